@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate the parity fixtures in tests/golden/*.npz by running the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference).  For each case it
+  1. writes the seeded synthetic checkpoints (audiodec_amd/synth.py) into a scratch root laid out
+     like the reference's repo root (exp/<tag>/config.yml + checkpoint-*.pkl, stats/*.npy),
+  2. imports the reference unchanged (a stub ``torchaudio`` is injected: it is imported at
+     bin/stream.py:17 and models/vocoder/modules/discriminator.py:23 but never called on this
+     path), loads it through its own ``AudioDec.load_transmitter / load_receiver`` on CPU and
+     streams seeded audio through ``encode -> quantize -> lookup -> decode`` (demoFile.py:58-61),
+     one reference instance per stream (the reference is batch-1 only),
+  3. asserts the CPU oracle (oracle/audiodec_oracle.py) reproduces the reference bit-for-bit here,
+  4. stores only the reference OUTPUTS (+ seeds/schedule); weights and audio are regenerated
+     from the seed wherever the tests run.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from audiodec_amd import configs, synth  # noqa: E402
+from oracle import audiodec_oracle as O  # noqa: E402
+
+SEED = 1337
+
+
+def import_reference():
+    ta = types.ModuleType("torchaudio")
+    ta.functional = types.ModuleType("torchaudio.functional")
+    ta.functional.spectrogram = None
+    ta.save = None
+    sys.modules.setdefault("torchaudio", ta)
+    sys.modules.setdefault("torchaudio.functional", ta.functional)
+    if REF not in sys.path:
+        sys.path.insert(1, REF)
+    import utils.audiodec as ref_audiodec
+    return ref_audiodec
+
+
+def load_reference(ref_audiodec, model):
+    sr, enc_ckpt, dec_ckpt = ref_audiodec.assign_model(model)
+    ad = ref_audiodec.AudioDec(tx_device="cpu", rx_device="cpu")
+    ad.load_transmitter(enc_ckpt)
+    ad.load_receiver(enc_ckpt, dec_ckpt)
+    return sr, ad
+
+
+def build_oracle(model, batch):
+    """Oracle twin of AudioDec.load_transmitter/load_receiver (bin/stream.py:56-77)."""
+    sr, enc_tag, _, dec_tag, _ = configs.alias(model)
+    mt_e, _, pe = configs.experiment(enc_tag)
+    mt_d, _, pd = configs.experiment(dec_tag)
+    sd_e = synth.synth_state_dict(enc_tag, SEED)
+    sd_d = synth.synth_state_dict(dec_tag, SEED)
+    tx = O.AutoEncoderOracle(sd_e, pe, batch)
+    tx.initial_encoder(8192)
+    rx = O.AutoEncoderOracle(sd_e, pe, 1)
+    zq0 = rx.initial_encoder(8192)
+    dec = O.build_decoder_oracle(sd_d, mt_d, pd, batch)
+    dec.initial_decoder(zq0)
+    return tx, rx, dec
+
+
+def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
+    torch.set_num_threads(4)
+    sr, ad = load_reference(ref_audiodec, model)
+    hop = ad.get_hop_length(ref_audiodec.assign_model(model)[1])
+    total = one_shot_len if one_shot_len is not None else sum(schedule) * hop
+    chunks = [one_shot_len] if one_shot_len is not None else [c * hop for c in schedule]
+    audio = np.stack([synth.synth_audio(SEED, s, total) for s in range(n_streams)])
+    zs, idxs, zqs, ys, margins = [], [], [], [], []
+    # reference: one freshly loaded instance per stream (identical warm-up state)
+    for s in range(n_streams):
+        inst = ad if s == 0 else load_reference(ref_audiodec, model)[1]
+        z_l, i_l, q_l, y_l = [], [], [], []
+        pos = 0
+        with torch.no_grad():
+            for c in chunks:
+                x = torch.from_numpy(audio[s, pos:pos + c])[None, None, :]
+                pos += c
+                z = inst.tx_encoder.encode(x)
+                idx = inst.tx_encoder.quantize(z)
+                zq = inst.rx_encoder.lookup(idx)
+                y = inst.decoder.decode(zq)
+                z_l.append(z); i_l.append(idx); q_l.append(zq); y_l.append(y)
+        zs.append(torch.cat(z_l, -1)[0]); idxs.append(torch.cat(i_l, -1))
+        zqs.append(torch.cat(q_l, 1)[0]); ys.append(torch.cat(y_l, -1)[0])
+    z = torch.stack(zs); idx = torch.stack(idxs, 1); zq = torch.stack(zqs); y = torch.stack(ys)
+    # oracle: one batch-1 instance per stream must agree bit-for-bit with the reference in this
+    # container; one batched instance (what the GPU parity tests use as the B-stream oracle) must
+    # agree to fp32 round-off (ATen picks a different conv kernel for batch > 1)
+    def run_oracle(streams):
+        tx, rx, dec = build_oracle(model, len(streams))
+        oz, oi, oq, oy, om = [], [], [], [], []
+        pos = 0
+        with torch.no_grad():
+            for c in chunks:
+                x = torch.from_numpy(audio[streams, pos:pos + c])[:, None, :]
+                pos += c
+                z_ = tx.encode(x)
+                i_, m_ = tx.quantize(z_, return_margin=True)
+                if len(streams) == 1:
+                    i_, m_ = i_[:, None], m_[:, None]
+                q_ = rx.lookup(i_)
+                y_ = dec.decode(q_)
+                oz.append(z_); oi.append(i_); oq.append(q_); oy.append(y_); om.append(m_)
+        return torch.cat(oz, -1), torch.cat(oi, -1), torch.cat(oq, 1), torch.cat(oy, -1), torch.cat(om, -1)
+
+    per = [run_oracle([s]) for s in range(n_streams)]
+    oz, oi, oq, oy, om = (torch.cat([p[k] for p in per], 1 if k in (1, 4) else 0) for k in range(5))
+    assert torch.equal(oi, idx), f"{name}: oracle indices differ from the reference"
+    for a, b, what in ((oz, z, "z"), (oq, zq, "zq"), (oy, y, "y")):
+        d = float((a - b).abs().max())
+        assert d == 0.0, f"{name}: oracle {what} differs from the reference by {d}"
+    if n_streams > 1:
+        bz, bi, bq, by, _ = run_oracle(list(range(n_streams)))
+        assert torch.equal(bi, idx), f"{name}: batched oracle indices differ from the reference"
+        print(f"  batched oracle vs reference: max|dz| {float((bz - z).abs().max()):.2e} "
+              f"max|dy| {float((by - y).abs().max()):.2e}")
+        assert float((by - y).abs().max()) < 2e-5
+    out = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(
+        out, model=model, seed=SEED, n_streams=n_streams, hop=hop, sample_rate=sr,
+        schedule=np.asarray(schedule if one_shot_len is None else [], np.int64),
+        one_shot_len=-1 if one_shot_len is None else one_shot_len,
+        z=z.numpy(), idx=idx.numpy(), zq=zq.numpy(), y=y.numpy(), margin=om.numpy())
+    print(f"{name}: frames {z.shape[-1]} z std {float(z.std()):.3f} |y|max {float(y.abs().max()):.3f} "
+          f"min top-2 margin {float(om.min()):.3e} distinct idx {len(torch.unique(idx))} "
+          f"-> {os.path.getsize(out)} B  (oracle == reference: exact)")
+
+
+def op_cases(ref_audiodec):
+    """Layer-level known answers from the reference's own layer classes (inputs: op_cases.py)."""
+    from layers.conv_layer import CausalConv1d, CausalConvTranspose1d
+    from layers.vq_module import ResidualVQ
+    sys.path.insert(0, HERE)
+    import op_cases as C
+    out = {}
+    for n, (ci, co, k, s, d, gr, b, L1, L2) in enumerate(C.CONVS):
+        x1, x2, w, bias = C.conv_inputs(n)
+        m = CausalConv1d(ci, co, k, s, d, gr, b).eval()
+        with torch.no_grad():
+            m.conv.weight.copy_(w)
+            if b:
+                m.conv.bias.copy_(bias)
+            y1 = m.inference(x1); y2 = m.inference(x2)
+            o1, p1 = O.causal_conv1d_inference(x1, torch.zeros(1, ci, (k - 1) * d), w, bias, s, d, gr)
+            o2, p2 = O.causal_conv1d_inference(x2, p1, w, bias, s, d, gr)
+        assert torch.equal(o1, y1) and torch.equal(o2, y2) and torch.equal(p2, m.pad_buffer)
+        out[f"conv{n}_y1"], out[f"conv{n}_y2"] = y1.numpy(), y2.numpy()
+        out[f"conv{n}_pad"] = m.pad_buffer.numpy()
+    for n, (ci, co, s, L1, L2) in enumerate(C.CONVTS):
+        x1, x2, w, bias = C.convt_inputs(n)
+        m = CausalConvTranspose1d(ci, co, 2 * s, s).eval()
+        with torch.no_grad():
+            m.deconv.weight.copy_(w); m.deconv.bias.copy_(bias)
+            y1 = m.inference(x1); y2 = m.inference(x2)
+            o1, p1 = O.causal_convtr1d_inference(x1, torch.zeros(1, ci, 1), w, bias, s)
+            o2, p2 = O.causal_convtr1d_inference(x2, p1, w, bias, s)
+        assert torch.equal(o1, y1) and torch.equal(o2, y2) and torch.equal(p2, m.pad_buffer)
+        out[f"convT{n}_y1"], out[f"convT{n}_y2"] = y1.numpy(), y2.numpy()
+        out[f"convT{n}_pad"] = m.pad_buffer.numpy()
+    # residual VQ incl. an engineered exact tie (lowest index must win, vq_module.py:98)
+    embeds, x = C.rvq_inputs()
+    rvq = ResidualVQ(dim=64, num_quantizers=C.RVQ_STAGES, codebook_size=1024).eval()
+    for l, e in zip(rvq.layers, embeds):
+        l.embed.copy_(e)
+    rvq.initial()
+    with torch.no_grad():
+        q, idx = rvq.forward_index(x.clone(), flatten_idx=True)
+        zq = rvq.lookup(idx)
+    oq, oi = O.rvq_forward_index(x, embeds, True)
+    assert torch.equal(oi, idx) and torch.equal(oq, q)
+    assert torch.equal(O.rvq_lookup(idx, O.rvq_codebook(embeds)), zq)
+    assert int(idx[0, 7]) == 123
+    out["rvq_idx"] = idx.numpy(); out["rvq_q"] = q.numpy(); out["rvq_zq"] = zq.numpy()
+    path = os.path.join(HERE, "ops.npz")
+    np.savez_compressed(path, **out)
+    print("ops:", len(out), "arrays ->", os.path.getsize(path), "B (oracle == reference: exact)")
+
+
+CASES = {
+    # name: (model alias, n_streams, chunk schedule in frames, one-shot length in samples)
+    "vctk_sym_stream": ("vctk_sym", 2, [1, 2, 1, 3], None),
+    "vctk_v1_stream": ("vctk_v1", 2, [1, 2, 1, 3], None),
+    "libritts_sym_file": ("libritts_sym", 1, None, 24000),          # BASELINE config 1 (demoFile)
+    "vctk_v0_stream": ("vctk_v0", 1, [1, 2], None),
+    "vctk_v2_stream": ("vctk_v2", 1, [1, 2], None),
+    "vctk_activate_sym_stream": ("vctk_activate_sym", 1, [1, 2], None),
+    "vctk_c16h320_sym_stream": ("vctk_c16h320_sym", 1, [1, 2], None),
+}
+
+
+def main(argv):
+    names = argv[1:] or (["ops"] + list(CASES))
+    ref_audiodec = import_reference()
+    with tempfile.TemporaryDirectory() as root:
+        os.chdir(root)
+        written = set()
+        for name in names:
+            if name == "ops":
+                op_cases(ref_audiodec)
+                continue
+            model, n, sched, one = CASES[name]
+            if model not in written:
+                synth.write_model(root, model, SEED)
+                written.add(model)
+            run_case(ref_audiodec, name, model, n, sched, one)
+        os.chdir(HERE)
+
+
+if __name__ == "__main__":
+    main(sys.argv)
