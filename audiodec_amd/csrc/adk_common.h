@@ -1,0 +1,44 @@
+// Internal helpers shared by the HIP translation units of libaudiodec_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/audiodec_hip.h"
+
+namespace adk {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define ADK_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return ::adk::fail(ADK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// Flattened arguments of one fused causal conv launch (see adk_causal_conv in the public header).
+struct ConvArgs {
+    const float* in;   int in_rows, in_ch, in_row0, in_choff, in_gstride;   // in_row0 = (cursor - hist) mod R
+    float* out;        int out_rows, out_ch, out_cursor, out_choff;
+    const float* res;  int res_rows, res_ch, res_cursor, res_choff, res_gstride;
+    const float* w;    const float* bias;
+    int cin_g, cout_g, groups, taps, stride, dilation, up, cout_real;
+    int act_in, act_out; float slope;
+    int batch, t_out, n_total;      // n_total = batch * t_out GEMM columns
+    int ktot;                       // taps * cin_g
+};
+
+__device__ __forceinline__ float act_apply(float x, int act, float slope) {
+    // torch.nn.ELU(alpha=1): x > 0 ? x : expm1(x); LeakyReLU: x > 0 ? x : x*slope; Tanh
+    if (act == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (act == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
+    if (act == ADK_ACT_TANH) return tanhf(x);
+    return x;
+}
+
+int launch_conv_direct(const ConvArgs& a, hipStream_t s);
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s);   // requires cin_g % 32 == 0 and 16-B alignment
+bool conv_mfma_supported(const ConvArgs& a);
+
+}  // namespace adk

@@ -1,0 +1,255 @@
+// Host side of libaudiodec_hip.so: error plumbing, the op-level conv entry point and the "program"
+// executor (fixed launch sequence of one model half over B streams with ring-buffer state).
+// Replaces the Python module traversal of StreamGenerator.encode/decode
+// (models/autoencoder/AudioDec.py:228-247, models/vocoder/HiFiGAN.py:268-296).
+#include "adk_common.h"
+#include <vector>
+#include <cstring>
+
+namespace adk {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+static int build_args(const adk_conv_desc& d, const adk_ring_view& in, const adk_ring_view& out,
+                      const adk_ring_view& res, int batch, int t_out, ConvArgs& a) {
+    if (!d.w || !in.base || !out.base) return fail(ADK_ERR_ARG, "conv: null weight/in/out pointer");
+    if (d.cin_g <= 0 || d.cout_g <= 0 || d.groups <= 0 || d.taps <= 0 || d.stride <= 0 || d.dilation <= 0 ||
+        d.up <= 0 || d.cout_real <= 0 || d.hist < 0)
+        return fail(ADK_ERR_SHAPE, "conv: non-positive geometry");
+    if (batch < 0 || t_out < 0) return fail(ADK_ERR_SHAPE, "conv: negative batch / t_out");
+    if ((long long)batch * t_out > 0x7fffffffLL) return fail(ADK_ERR_SHAPE, "conv: batch * t_out overflows");
+    const long long M = (long long)d.groups * d.cout_g;
+    if (M != (long long)d.up * d.cout_real) return fail(ADK_ERR_SHAPE, "conv: groups*cout_g != up*cout_real");
+    if (d.up > 1 && d.groups != 1) return fail(ADK_ERR_SHAPE, "conv: transposed form needs groups == 1");
+    // input window [cursor - hist, cursor - hist + (t_out-1)*stride + (taps-1)*dilation] must fit the ring
+    const long long span = (long long)(t_out > 0 ? (t_out - 1) : 0) * d.stride + (long long)(d.taps - 1) * d.dilation + 1;
+    if (span > in.rows || d.hist >= in.rows + 1) return fail(ADK_ERR_SHAPE, "conv: input window exceeds the ring");
+    if (in.cursor < 0 || in.cursor >= in.rows || out.cursor < 0 || out.cursor >= out.rows)
+        return fail(ADK_ERR_SHAPE, "conv: cursor outside ring");
+    if ((long long)t_out * d.up > out.rows) return fail(ADK_ERR_SHAPE, "conv: output rows exceed the ring");
+    if (in.ch_off < 0 || in.ch_off + (long long)(d.groups - 1) * d.in_group_stride + d.cin_g > in.channels)
+        return fail(ADK_ERR_SHAPE, "conv: input channels exceed the ring row");
+    if (out.ch_off < 0 || out.ch_off + d.cout_real > out.channels)
+        return fail(ADK_ERR_SHAPE, "conv: output channels exceed the ring row");
+    if (res.base) {
+        if (d.up != 1) return fail(ADK_ERR_SHAPE, "conv: residual add needs up == 1");
+        if (res.cursor < 0 || res.cursor >= res.rows || t_out > res.rows)
+            return fail(ADK_ERR_SHAPE, "conv: residual cursor/rows");
+        if (res.ch_off < 0 || res.ch_off + (long long)(d.groups - 1) * d.res_group_stride + d.cout_g > res.channels)
+            return fail(ADK_ERR_SHAPE, "conv: residual channels exceed the ring row");
+    }
+    if (d.act_in < 0 || d.act_in > ADK_ACT_TANH || d.act_out < 0 || d.act_out > ADK_ACT_TANH)
+        return fail(ADK_ERR_ARG, "conv: unknown activation");
+    a.in = in.base; a.in_rows = in.rows; a.in_ch = in.channels; a.in_choff = in.ch_off; a.in_gstride = d.in_group_stride;
+    a.in_row0 = ((in.cursor - d.hist) % in.rows + in.rows) % in.rows;
+    a.out = out.base; a.out_rows = out.rows; a.out_ch = out.channels; a.out_cursor = out.cursor; a.out_choff = out.ch_off;
+    a.res = res.base; a.res_rows = res.rows; a.res_ch = res.channels; a.res_cursor = res.cursor; a.res_choff = res.ch_off;
+    a.res_gstride = d.res_group_stride;
+    a.w = d.w; a.bias = d.bias;
+    a.cin_g = d.cin_g; a.cout_g = d.cout_g; a.groups = d.groups; a.taps = d.taps; a.stride = d.stride;
+    a.dilation = d.dilation; a.up = d.up; a.cout_real = d.cout_real;
+    a.act_in = d.act_in; a.act_out = d.act_out; a.slope = d.act_in_slope;
+    a.batch = batch; a.t_out = t_out; a.n_total = batch * t_out; a.ktot = d.taps * d.cin_g;
+    return ADK_OK;
+}
+
+static int run_conv(const ConvArgs& a, int impl, hipStream_t s) {
+    if (impl == ADK_IMPL_DIRECT) return launch_conv_direct(a, s);
+    const bool ok = conv_mfma_supported(a);
+    if (impl == ADK_IMPL_MFMA) {
+        if (!ok) return fail(ADK_ERR_SHAPE, "conv: MFMA kernel needs cin_g % 32 == 0 and 16-byte aligned rows");
+        return launch_conv_mfma(a, s);
+    }
+    // AUTO: matrix cores whenever the shape is GEMM-like; tiny M (Cout == 1) stays on the VALU kernel
+    if (ok && a.groups * a.cout_g >= 32) return launch_conv_mfma(a, s);
+    return launch_conv_direct(a, s);
+}
+
+}  // namespace adk
+
+using namespace adk;
+
+extern "C" const char* adk_last_error(void) { return g_err.c_str(); }
+extern "C" int adk_abi_version(void) { return ADK_ABI_VERSION; }
+
+extern "C" int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
+                               int32_t batch, int32_t t_out, int32_t impl, void* stream) {
+    if (!d) return fail(ADK_ERR_ARG, "adk_causal_conv: null descriptor");
+    ConvArgs a;
+    int rc = build_args(*d, in, out, res, batch, t_out, a);
+    if (rc != ADK_OK) return rc;
+    return run_conv(a, impl, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct adk_program {
+    std::vector<adk_op_desc> ops;
+    std::vector<adk_ring_desc> rings;
+    std::vector<int32_t> rows;      // ring length (arena rings)
+    std::vector<int32_t> cursor;
+    int batch = 0, max_frames = 0, n_ext = 0;
+    const float* weights = nullptr; int64_t weights_floats = 0;
+    float* arena = nullptr; int64_t arena_floats = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
+    std::vector<float> last_ms;
+};
+
+extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const adk_ring_desc* rings, int32_t n_rings,
+                                  int32_t batch, int32_t max_frames, const float* weights, int64_t weights_floats,
+                                  float* arena, int64_t arena_floats, adk_program** out) {
+    if (!ops || !rings || !out || n_ops <= 0 || n_rings <= 0) return fail(ADK_ERR_ARG, "program_create: null/empty input");
+    if (batch <= 0 || max_frames <= 0) return fail(ADK_ERR_SHAPE, "program_create: batch and max_frames must be positive");
+    if (!weights || !arena) return fail(ADK_ERR_ARG, "program_create: null weights/arena");
+    adk_program* p = new adk_program();
+    p->ops.assign(ops, ops + n_ops);
+    p->rings.assign(rings, rings + n_rings);
+    p->rows.resize(n_rings); p->cursor.assign(n_rings, 0);
+    p->batch = batch; p->max_frames = max_frames;
+    p->weights = weights; p->weights_floats = weights_floats; p->arena = arena; p->arena_floats = arena_floats;
+    auto bail = [&](int code, const std::string& m) { delete p; return fail(code, m); };
+    for (int i = 0; i < n_rings; ++i) {
+        const adk_ring_desc& r = rings[i];
+        if (r.channels <= 0 || r.hist < 0 || r.rate <= 0) return bail(ADK_ERR_SHAPE, "program_create: bad ring desc");
+        if (r.external >= 0) {
+            if (r.hist != 0) return bail(ADK_ERR_SHAPE, "program_create: external rings carry no history");
+            p->rows[i] = 0;
+            if (r.external + 1 > p->n_ext) p->n_ext = r.external + 1;
+        } else {
+            const long long rows = (long long)r.hist + (long long)max_frames * r.rate;
+            if (rows > 0x7fffffffLL) return bail(ADK_ERR_SHAPE, "program_create: ring too long");
+            p->rows[i] = (int32_t)rows;
+            const long long need = r.arena_off + (long long)batch * rows * r.channels;
+            if (r.arena_off < 0 || r.arena_off % 4 || need > arena_floats)
+                return bail(ADK_ERR_SHAPE, "program_create: ring does not fit the arena (or offset not 16-byte aligned)");
+        }
+    }
+    for (int i = 0; i < n_ops; ++i) {
+        const adk_op_desc& o = ops[i];
+        auto ring_ok = [&](int id) { return id >= 0 && id < n_rings; };
+        if (o.kind == ADK_OP_CONV) {
+            if (!ring_ok(o.in_ring) || !ring_ok(o.out_ring) || (o.res_ring >= 0 && !ring_ok(o.res_ring)))
+                return bail(ADK_ERR_ARG, "program_create: op references an unknown ring");
+            const long long wn = (long long)o.conv.groups * o.conv.cout_g * o.conv.taps * o.conv.cin_g;
+            if (o.w_off < 0 || o.w_off % 4 || o.w_off + wn > weights_floats) return bail(ADK_ERR_SHAPE, "program_create: weight offset out of range");
+            if (o.b_off >= 0 && (o.b_off % 4 || o.b_off + (long long)o.conv.groups * o.conv.cout_g > weights_floats))
+                return bail(ADK_ERR_SHAPE, "program_create: bias offset out of range");
+            if (o.rate_out <= 0) return bail(ADK_ERR_SHAPE, "program_create: rate_out must be positive");
+            if (o.conv.hist > rings[o.in_ring].hist) return bail(ADK_ERR_SHAPE, "program_create: op needs more history than its ring keeps");
+        } else if (o.kind == ADK_OP_RING_WRITE) {
+            if (!ring_ok(o.out_ring) || o.ext_src < 0) return bail(ADK_ERR_ARG, "program_create: ring_write needs out_ring and ext_src");
+            if (o.ext_src + 1 > p->n_ext) p->n_ext = o.ext_src + 1;
+            if ((o.mean_off >= 0) != (o.scale_off >= 0)) return bail(ADK_ERR_ARG, "program_create: mean and scale go together");
+        } else {
+            return bail(ADK_ERR_ARG, "program_create: unknown op kind");
+        }
+    }
+    *out = p;
+    return ADK_OK;
+}
+
+extern "C" void adk_program_destroy(adk_program* p) {
+    if (!p) return;
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+}
+
+static adk_ring_view view_of(const adk_program* p, int id, int frames, void* const* ext, int ch_off) {
+    adk_ring_view v;
+    const adk_ring_desc& r = p->rings[id];
+    v.channels = r.channels; v.ch_off = ch_off;
+    if (r.external >= 0) {
+        v.base = static_cast<float*>(ext[r.external]);
+        v.rows = frames * r.rate; v.cursor = 0;
+    } else {
+        v.base = p->arena + r.arena_off; v.rows = p->rows[id]; v.cursor = p->cursor[id];
+    }
+    return v;
+}
+
+extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream) {
+    if (!p) return fail(ADK_ERR_ARG, "program_step: null program");
+    if (frames <= 0 || frames > p->max_frames) return fail(ADK_ERR_SHAPE, "program_step: frames must be in [1, max_frames]");
+    if (n_ext < p->n_ext || (p->n_ext > 0 && !ext)) return fail(ADK_ERR_ARG, "program_step: missing external buffers");
+    for (int i = 0; i < p->n_ext; ++i)
+        if (!ext[i]) return fail(ADK_ERR_ARG, "program_step: null external buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int n_ops = (int)p->ops.size();
+    if (p->profiling && (int)p->ev.size() != n_ops + 1) {
+        for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+        p->ev.resize(n_ops + 1);
+        for (auto& e : p->ev) ADK_HIP_CHECK(hipEventCreate(&e));
+    }
+    if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[0], s));
+    for (int i = 0; i < n_ops; ++i) {
+        const adk_op_desc& o = p->ops[i];
+        if (o.kind == ADK_OP_CONV) {
+            adk_conv_desc d = o.conv;
+            d.w = p->weights + o.w_off;
+            d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
+            adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
+            adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
+            adk_ring_view res; memset(&res, 0, sizeof(res));
+            if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
+            ConvArgs a;
+            int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+            if (rc == ADK_OK) rc = run_conv(a, o.impl, s);
+            if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+        } else {
+            adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
+            const float* mean = o.mean_off >= 0 ? p->weights + o.mean_off : nullptr;
+            const float* scale = o.scale_off >= 0 ? p->weights + o.scale_off : nullptr;
+            int rc = adk_ring_write(static_cast<const float*>(ext[o.ext_src]), out, mean, scale, p->batch,
+                                    frames * p->rings[o.out_ring].rate, stream);
+            if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+        }
+        if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[i + 1], s));
+    }
+    for (size_t i = 0; i < p->rings.size(); ++i)
+        if (p->rings[i].external < 0)
+            p->cursor[i] = (int32_t)(((long long)p->cursor[i] + (long long)frames * p->rings[i].rate) % p->rows[i]);
+    return ADK_OK;
+}
+
+extern "C" int adk_program_reset(adk_program* p, void* stream) {
+    if (!p) return fail(ADK_ERR_ARG, "program_reset: null program");
+    for (size_t i = 0; i < p->rings.size(); ++i) {
+        const adk_ring_desc& r = p->rings[i];
+        if (r.external >= 0) continue;
+        ADK_HIP_CHECK(hipMemsetAsync(p->arena + r.arena_off, 0, sizeof(float) * (size_t)p->batch * p->rows[i] * r.channels,
+                                     static_cast<hipStream_t>(stream)));
+        p->cursor[i] = 0;
+    }
+    return ADK_OK;
+}
+
+extern "C" int adk_program_get_cursors(const adk_program* p, int32_t* cursors, int32_t n) {
+    if (!p || !cursors || n != (int)p->cursor.size()) return fail(ADK_ERR_ARG, "program_get_cursors: bad arguments");
+    memcpy(cursors, p->cursor.data(), sizeof(int32_t) * n);
+    return ADK_OK;
+}
+
+extern "C" int adk_program_set_cursors(adk_program* p, const int32_t* cursors, int32_t n) {
+    if (!p || !cursors || n != (int)p->cursor.size()) return fail(ADK_ERR_ARG, "program_set_cursors: bad arguments");
+    for (int i = 0; i < n; ++i)
+        if (p->rings[i].external < 0 && (cursors[i] < 0 || cursors[i] >= p->rows[i]))
+            return fail(ADK_ERR_SHAPE, "program_set_cursors: cursor outside ring");
+    memcpy(p->cursor.data(), cursors, sizeof(int32_t) * n);
+    return ADK_OK;
+}
+
+extern "C" int adk_program_set_profiling(adk_program* p, int32_t enabled) {
+    if (!p) return fail(ADK_ERR_ARG, "program_set_profiling: null program");
+    p->profiling = enabled != 0;
+    return ADK_OK;
+}
+
+extern "C" int adk_program_last_op_ms(adk_program* p, float* ms, int32_t n) {
+    if (!p || !ms || n != (int)p->ops.size()) return fail(ADK_ERR_ARG, "program_last_op_ms: bad arguments");
+    if (!p->profiling || (int)p->ev.size() != n + 1) return fail(ADK_ERR_STATE, "program_last_op_ms: profiling not enabled / no step yet");
+    ADK_HIP_CHECK(hipEventSynchronize(p->ev[n]));
+    for (int i = 0; i < n; ++i) ADK_HIP_CHECK(hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
+    return ADK_OK;
+}

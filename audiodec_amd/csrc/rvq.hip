@@ -1,0 +1,211 @@
+// Residual-VQ encode / lookup and the ring writer.
+//   encode: ResidualVQ.forward_index over VectorQuantize.forward_index (layers/vq_module.py:136-149, 90-104)
+//   lookup: ResidualVQ.lookup (layers/vq_module.py:159-161)
+//   ring_write: torch.cat of new rows onto the state (layers/conv_layer.py:154) + HiFiGAN decode_norm
+//               (models/vocoder/HiFiGAN.py:276-279)
+#include "adk_common.h"
+
+namespace adk {
+
+constexpr int RVQ_DIM_MAX = 128;
+
+__device__ int g_adk_flags = 0;      // bit 0: rvq_lookup saw an out-of-range index
+
+// (value, index) arg-max with "greater value, else smaller index" -- matches `(-dist).max(1)` on the
+// reference's CPU path, which returns the lowest index among equal maxima.
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float v2, int i2) {
+    if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+
+// One workgroup = RB rows (b,t) x all codes; 4 consecutive codes per thread per 1024-code slab, so
+// the codebook (dim-major, codes contiguous: the reference's `embed` layout) is read with coalesced
+// float4 loads and every loaded value is reused for RB rows.  The 8 stages stay inside one launch
+// because stage i+1 needs r - q'_i.  Wave-level (value,index) reduction by DPP/shuffle, then LDS
+// across the 4 waves.
+template <int RB>
+__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ z, const float* __restrict__ embed,
+                                                         const float* __restrict__ enorm, long long* __restrict__ idx,
+                                                         float* __restrict__ zq, int n_rows, int n_q, int dim, int size) {
+    __shared__ float r_sh[RB][RVQ_DIM_MAX];
+    __shared__ float q_sh[RB][RVQ_DIM_MAX];
+    __shared__ float rn_sh[RB];
+    __shared__ float red_v[RB][4];
+    __shared__ int red_i[RB][4];
+    __shared__ int best_sh[RB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * RB;
+    for (int e = tid; e < RB * dim; e += 256) {
+        const int rr = e / dim, d = e - rr * dim;
+        r_sh[rr][d] = (row0 + rr < n_rows) ? z[(size_t)(row0 + rr) * dim + d] : 0.f;
+        q_sh[rr][d] = 0.f;
+    }
+    __syncthreads();
+    for (int st = 0; st < n_q; ++st) {
+        const float* E = embed + (size_t)st * dim * size;
+        const float* EN = enorm + (size_t)st * size;
+        if (tid < RB) {                                   // flatten.pow(2).sum(1)   (vq_module.py:94)
+            float s = 0.f;
+            for (int d = 0; d < dim; ++d) s = __fadd_rn(s, __fmul_rn(r_sh[tid][d], r_sh[tid][d]));
+            rn_sh[tid] = s;
+        }
+        __syncthreads();
+        float bv[RB]; int bi[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) { bv[rr] = -INFINITY; bi[rr] = 0x7fffffff; }
+        for (int cb = 0; cb < size; cb += 1024) {
+            const int c0 = cb + 4 * tid;
+            if (c0 >= size) break;
+            float acc[RB][4];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) acc[rr][0] = acc[rr][1] = acc[rr][2] = acc[rr][3] = 0.f;
+            for (int d = 0; d < dim; ++d) {               // (2*flatten) @ embed   (vq_module.py:95)
+                const float4 e4 = *reinterpret_cast<const float4*>(E + (size_t)d * size + c0);
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const float x2 = 2.f * r_sh[rr][d];
+                    acc[rr][0] = fmaf(x2, e4.x, acc[rr][0]);
+                    acc[rr][1] = fmaf(x2, e4.y, acc[rr][1]);
+                    acc[rr][2] = fmaf(x2, e4.z, acc[rr][2]);
+                    acc[rr][3] = fmaf(x2, e4.w, acc[rr][3]);
+                }
+            }
+            const float4 en = *reinterpret_cast<const float4*>(EN + c0);
+            const float env[4] = {en.x, en.y, en.z, en.w};
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {             // dist = (|r|^2 - 2rE) + |E|^2 ; argmax(-dist)
+                    const float dist = __fadd_rn(__fsub_rn(rn_sh[rr], acc[rr][c]), env[c]);
+                    argmax_merge(bv[rr], bi[rr], -dist, c0 + c);
+                }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            float v = bv[rr]; int i = bi[rr];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float v2 = __shfl_xor(v, off, 64);
+                const int i2 = __shfl_xor(i, off, 64);
+                argmax_merge(v, i, v2, i2);
+            }
+            if (lane == 0) { red_v[rr][wave] = v; red_i[rr][wave] = i; }
+        }
+        __syncthreads();
+        if (tid < RB) {
+            float v = red_v[tid][0]; int i = red_i[tid][0];
+            for (int w = 1; w < 4; ++w) argmax_merge(v, i, red_v[tid][w], red_i[tid][w]);
+            best_sh[tid] = i;
+            if (row0 + tid < n_rows) idx[(size_t)st * n_rows + row0 + tid] = (long long)i + (long long)size * st;
+        }
+        __syncthreads();
+        for (int e = tid; e < RB * dim; e += 256) {       // straight-through + residual (vq_module.py:101-102,143-144)
+            const int rr = e / dim, d = e - rr * dim;
+            const float r = r_sh[rr][d];
+            const float q = E[(size_t)d * size + best_sh[rr]];
+            const float qp = __fadd_rn(r, __fsub_rn(q, r));
+            r_sh[rr][d] = __fsub_rn(r, qp);
+            q_sh[rr][d] = __fadd_rn(q_sh[rr][d], qp);
+        }
+        __syncthreads();
+    }
+    if (zq)
+        for (int e = tid; e < RB * dim; e += 256) {
+            const int rr = e / dim, d = e - rr * dim;
+            if (row0 + rr < n_rows) zq[(size_t)(row0 + rr) * dim + d] = q_sh[rr][d];
+        }
+}
+
+__global__ __launch_bounds__(256) void rvq_lookup_kernel(const long long* __restrict__ idx, const float* __restrict__ codebook,
+                                                         float* __restrict__ zq, int n_rows, int n_q, int dim, int n_codes) {
+    const int d4 = dim / 4;
+    const long long total = (long long)n_rows * d4;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(gid / d4), c = (int)(gid - (long long)row * d4);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < n_q; ++q) {                    // torch.sum(F.embedding(idx, codebook), dim=0)
+            long long i = idx[(size_t)q * n_rows + row];
+            if (i < 0 || i >= n_codes) { atomicOr(&g_adk_flags, 1); i = 0; }
+            const float4 e = *reinterpret_cast<const float4*>(codebook + (size_t)i * dim + 4 * c);
+            s.x = __fadd_rn(s.x, e.x); s.y = __fadd_rn(s.y, e.y); s.z = __fadd_rn(s.z, e.z); s.w = __fadd_rn(s.w, e.w);
+        }
+        *reinterpret_cast<float4*>(zq + (size_t)row * dim + 4 * c) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void ring_write_kernel(const float* __restrict__ src, float* __restrict__ ring, int rows, int channels,
+                                                         int cursor, int ch_off, int src_ch, const float* __restrict__ mean,
+                                                         const float* __restrict__ scale, int batch, int t) {
+    const long long total = (long long)batch * t * src_ch;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % src_ch);
+        const long long bt = gid / src_ch;
+        const int tt = (int)(bt % t), b = (int)(bt / t);
+        float v = src[gid];
+        if (mean) v = __fdiv_rn(__fsub_rn(v, mean[c]), scale[c]);      // (c - mean) / scale, true division
+        int row = cursor + tt;
+        if (row >= rows) row -= rows;
+        ring[((size_t)b * rows + row) * channels + ch_off + c] = v;
+    }
+}
+
+}  // namespace adk
+
+using namespace adk;
+
+extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* enorm, int64_t* idx, float* zq,
+                              int32_t n_rows, int32_t n_q, int32_t dim, int32_t size, void* stream) {
+    if (!z || !embed || !enorm || !idx) return fail(ADK_ERR_ARG, "adk_rvq_encode: null pointer");
+    if (n_rows < 0 || n_q <= 0 || dim <= 0 || dim > RVQ_DIM_MAX || size <= 0 || size % 4)
+        return fail(ADK_ERR_SHAPE, "adk_rvq_encode: need 0 < dim <= 128, size % 4 == 0, n_q > 0");
+    if ((reinterpret_cast<uintptr_t>(embed) | reinterpret_cast<uintptr_t>(enorm)) & 15)
+        return fail(ADK_ERR_ARG, "adk_rvq_encode: embed/enorm must be 16-byte aligned");
+    if (n_rows == 0) return ADK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int RB = 4;
+    hipLaunchKernelGGL(rvq_encode_kernel<RB>, dim3((n_rows + RB - 1) / RB), dim3(256), 0, s, z, embed, enorm,
+                       reinterpret_cast<long long*>(idx), zq, n_rows, n_q, dim, size);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
+extern "C" int adk_rvq_lookup(const int64_t* idx, const float* codebook, float* zq, int32_t n_rows, int32_t n_q,
+                              int32_t dim, int32_t n_codes, void* stream) {
+    if (!idx || !codebook || !zq) return fail(ADK_ERR_ARG, "adk_rvq_lookup: null pointer");
+    if (n_rows < 0 || n_q <= 0 || dim <= 0 || dim % 4 || n_codes <= 0) return fail(ADK_ERR_SHAPE, "adk_rvq_lookup: bad shape");
+    if ((reinterpret_cast<uintptr_t>(codebook) | reinterpret_cast<uintptr_t>(zq)) & 15)
+        return fail(ADK_ERR_ARG, "adk_rvq_lookup: codebook/zq must be 16-byte aligned");
+    if (n_rows == 0) return ADK_OK;
+    const long long total = (long long)n_rows * (dim / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rvq_lookup_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(idx), codebook, zq, n_rows, n_q, dim, n_codes);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
+extern "C" int adk_ring_write(const float* src, adk_ring_view ring, const float* mean, const float* scale,
+                              int32_t batch, int32_t t, void* stream) {
+    if (!src || !ring.base) return fail(ADK_ERR_ARG, "adk_ring_write: null pointer");
+    if ((mean == nullptr) != (scale == nullptr)) return fail(ADK_ERR_ARG, "adk_ring_write: mean and scale go together");
+    if (batch < 0 || t < 0 || t > ring.rows || ring.cursor < 0 || ring.cursor >= ring.rows || ring.ch_off != 0)
+        return fail(ADK_ERR_SHAPE, "adk_ring_write: bad ring geometry (full rows only: ch_off must be 0)");
+    if (batch == 0 || t == 0) return ADK_OK;
+    const int src_ch = ring.channels;
+    const long long total = (long long)batch * t * src_ch;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ring_write_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                       ring.base, ring.rows, ring.channels, ring.cursor, ring.ch_off, src_ch, mean, scale, batch, t);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
+extern "C" int adk_debug_flags(int32_t* out) {
+    int v = 0;
+    ADK_HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(adk::g_adk_flags), sizeof(int)));
+    int zero = 0;
+    ADK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(adk::g_adk_flags), &zero, sizeof(int)));
+    if (out) *out = v;
+    return ADK_OK;
+}

@@ -1,0 +1,122 @@
+"""ctypes binding of libaudiodec_hip.so (C ABI: include/audiodec_hip.h).
+
+There is no CPU fallback: if the shared library is missing or does not export the ABI this module
+raises, and so does everything that computes.  The library is built in-tree by
+``__graft_entry__.build()`` (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaudiodec_hip.so")
+ABI_VERSION = 1
+
+ADK_OK = 0
+ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+OP_CONV, OP_RING_WRITE = 0, 1
+
+
+class RingView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("rows", C.c_int32), ("channels", C.c_int32),
+                ("cursor", C.c_int32), ("ch_off", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("cin_g", C.c_int32), ("cout_g", C.c_int32), ("groups", C.c_int32),
+                ("taps", C.c_int32), ("stride", C.c_int32), ("dilation", C.c_int32),
+                ("hist", C.c_int32), ("up", C.c_int32), ("cout_real", C.c_int32),
+                ("in_group_stride", C.c_int32), ("res_group_stride", C.c_int32),
+                ("act_in", C.c_int32), ("act_in_slope", C.c_float), ("act_out", C.c_int32),
+                ("w", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class RingDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("hist", C.c_int32), ("rate", C.c_int32),
+                ("external", C.c_int32), ("arena_off", C.c_int64)]
+
+
+class OpDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_ring", C.c_int32), ("out_ring", C.c_int32), ("res_ring", C.c_int32),
+                ("in_ch_off", C.c_int32), ("out_ch_off", C.c_int32), ("res_ch_off", C.c_int32),
+                ("rate_out", C.c_int32), ("conv", ConvDesc), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("mean_off", C.c_int64), ("scale_off", C.c_int64), ("ext_src", C.c_int32), ("impl", C.c_int32)]
+
+
+# every symbol include/audiodec_hip.h declares: (restype, argtypes)
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+SYMBOLS = {
+    "adk_last_error": (C.c_char_p, []),
+    "adk_abi_version": (C.c_int, []),
+    "adk_debug_flags": (C.c_int, [C.POINTER(_i32)]),
+    "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
+    "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),
+    "adk_rvq_encode": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "adk_rvq_lookup": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "adk_program_create": (C.c_int, [C.POINTER(OpDesc), _i32, C.POINTER(RingDesc), _i32, _i32, _i32, _vp, _i64,
+                                     _vp, _i64, C.POINTER(_vp)]),
+    "adk_program_destroy": (None, [_vp]),
+    "adk_program_step": (C.c_int, [_vp, _i32, C.POINTER(_vp), _i32, _vp]),
+    "adk_program_reset": (C.c_int, [_vp, _vp]),
+    "adk_program_get_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
+    "adk_program_set_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
+    "adk_program_set_profiling": (C.c_int, [_vp, _i32]),
+    "adk_program_last_op_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises NativeError if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} is missing: the AudioDec HIP kernels are not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback.")
+    import torch  # noqa: F401  -- loads the HIP runtime (libamdhip64.so.7) this library binds to
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise NativeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if l.adk_abi_version() != ABI_VERSION:
+        raise NativeError(f"{LIB_PATH}: ABI version {l.adk_abi_version()} != {ABI_VERSION}; rebuild it")
+    _lib = l
+    return l
+
+
+def check(rc, what=""):
+    if rc != ADK_OK:
+        msg = lib().adk_last_error().decode(errors="replace")
+        if rc in (-1, -2):
+            raise ValueError(f"{what}: {msg} (adk error {rc})")
+        raise NativeError(f"{what}: {msg} (adk error {rc})")
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu(device):
+    """The product path runs on a HIP device only."""
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise NativeError(f"device {device!r}: the AudioDec HIP path needs a 'cuda:N' (HIP) device; "
+                          "there is no CPU implementation in this package")
+    if not torch.cuda.is_available():
+        raise NativeError("no HIP device visible (torch.cuda.is_available() is False)")
+    lib()
+    return dev

@@ -1,0 +1,355 @@
+"""Lowering of the reference's module graphs to ring-buffer launch programs.
+
+The reference walks Python modules per call (StreamGenerator.encode/decode,
+/root/reference/models/autoencoder/AudioDec.py:228-247, models/vocoder/HiFiGAN.py:268-296).  Here
+each model half is lowered once, at load time, to a flat list of fused causal-conv ops over
+channel-last state rings (include/audiodec_hip.h) and executed by the C++ program runner.
+
+Lowering rules (reference semantics preserved op for op):
+  * a CausalConv1d / CausalConvTranspose1d input + its pad_buffer  -> one ring with `hist` rows
+    (layers/conv_layer.py:141,153-156 / :182,194-197); the ring holds the RAW signal, the consumer
+    applies the activation the reference applied before the conv
+  * transposed conv (K = 2*stride)  -> polyphase 2-tap conv with s*Cout GEMM rows
+  * x + conv2(act(conv1(act(x))))   -> conv1 into a scratch ring, 1x1 conv with residual epilogue
+    (models/autoencoder/modules/residual_unit.py:78-81)
+  * MultiGroupConv1d: x.repeat(1,3,1) is never materialised: group stride 0 on the first conv's
+    input and on the first residual (models/vocoder/modules/multi_fusion.py:133-141)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import arch, native
+from .native import (ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_TANH, IMPL_AUTO, OP_CONV, OP_RING_WRITE,
+                     ConvDesc, OpDesc, RingDesc)
+
+
+# ---------------------------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------------------------
+def effective_weight(sd, spec):
+    """Fold weight-norm exactly as the reference's forward pre-hook does (torch._weight_norm, dim 0)."""
+    if spec.wn:
+        return torch._weight_norm(sd[spec.wkey("weight_v")].float(), sd[spec.wkey("weight_g")].float(), 0)
+    return sd[spec.wkey("weight")].float()
+
+
+def pack_conv(w):
+    """(Cout, Cin/g, K) -> [Cout][K*Cin/g]  (tap-major, channel-minor GEMM rows)."""
+    co, ci, k = w.shape
+    return w.permute(0, 2, 1).reshape(co, k * ci).contiguous()
+
+
+def pack_convtr(w, stride):
+    """ConvTranspose1d weight (Cin, Cout, 2s) -> polyphase GEMM rows [(r*Cout+co)][(j, ci)].
+
+    y[co, t*s+r] = b[co] + sum_ci x[ci,t-1]*W[ci,co,s+r] + x[ci,t]*W[ci,co,r]   (tap 0 = older row).
+    """
+    ci, co, k = w.shape
+    assert k == 2 * stride
+    old = w[:, :, stride:].permute(2, 1, 0)     # (r, co, ci): multiplies x[t-1]
+    new = w[:, :, :stride].permute(2, 1, 0)     # (r, co, ci): multiplies x[t]
+    return torch.cat([old, new], dim=2).reshape(stride * co, 2 * ci).contiguous()
+
+
+class Blob:
+    """Packed fp32 weights; every tensor starts on a 16-byte boundary."""
+
+    def __init__(self):
+        self.parts, self.n = [], 0
+
+    def add(self, t):
+        t = t.detach().float().contiguous().reshape(-1)
+        off = self.n
+        pad = (-t.numel()) % 4
+        self.parts.append(t)
+        if pad:
+            self.parts.append(torch.zeros(pad))
+        self.n += t.numel() + pad
+        return off
+
+    def tensor(self):
+        return torch.cat(self.parts) if self.parts else torch.zeros(4)
+
+
+# ---------------------------------------------------------------------------------------------
+# program builder
+# ---------------------------------------------------------------------------------------------
+class Builder:
+    def __init__(self, sd, specs):
+        self.sd = sd
+        self.specs = arch.by_name(specs)
+        self.blob = Blob()
+        self.rings, self.ops, self.op_names = [], [], []
+        self.scratch = {}
+        self.flops_per_frame = 0
+
+    def ring(self, channels, hist, rate, external=-1):
+        self.rings.append(dict(channels=channels, hist=hist, rate=rate, external=external))
+        return len(self.rings) - 1
+
+    def scratch_ring(self, channels, rate, tag=""):
+        key = (channels, rate, tag)
+        if key not in self.scratch:
+            self.scratch[key] = self.ring(channels, 0, rate)
+        return self.scratch[key]
+
+    def need_hist(self, ring_id, hist):
+        r = self.rings[ring_id]
+        assert r["external"] < 0 or hist == 0
+        r["hist"] = max(r["hist"], hist)
+
+    def ring_write(self, out_ring, ext_src, mean=None, scale=None):
+        op = OpDesc()
+        op.kind = OP_RING_WRITE
+        op.in_ring, op.out_ring, op.res_ring = -1, out_ring, -1
+        op.ext_src = ext_src
+        op.mean_off = self.blob.add(mean) if mean is not None else -1
+        op.scale_off = self.blob.add(scale) if scale is not None else -1
+        op.w_off, op.b_off = 0, -1
+        op.rate_out = self.rings[out_ring]["rate"]
+        self.ops.append(op)
+        self.op_names.append("ring_write")
+
+    def conv(self, name, in_ring, out_ring, act_in=ACT_NONE, slope=0.0, act_out=ACT_NONE, res_ring=-1,
+             in_group_stride=None, res_group_stride=None, impl=IMPL_AUTO):
+        s = self.specs[name]
+        w = effective_weight(self.sd, s)
+        bias = self.sd[s.wkey("bias")].float() if s.bias else None
+        d = ConvDesc()
+        rin, rout = self.rings[in_ring], self.rings[out_ring]
+        if s.kind == "convT":
+            packed = pack_convtr(w, s.stride)
+            d.cin_g, d.cout_g, d.groups = s.cin, s.stride * s.cout, 1
+            d.taps, d.stride, d.dilation, d.hist = 2, 1, 1, 1
+            d.up, d.cout_real = s.stride, s.cout
+            if bias is not None:
+                bias = bias.repeat(s.stride)
+            rate_out = rin["rate"]
+            assert rout["rate"] == rin["rate"] * s.stride
+        else:
+            packed = pack_conv(w)
+            d.cin_g, d.cout_g, d.groups = s.cin // s.groups, s.cout // s.groups, s.groups
+            d.taps, d.stride, d.dilation, d.hist = s.k, s.stride, s.dilation, s.pad
+            d.up, d.cout_real = 1, s.cout
+            assert rin["rate"] % s.stride == 0 and rout["rate"] == rin["rate"] // s.stride, name
+            rate_out = rout["rate"]
+        d.in_group_stride = d.cin_g if in_group_stride is None else in_group_stride
+        d.res_group_stride = d.cout_g if res_group_stride is None else res_group_stride
+        d.act_in, d.act_in_slope, d.act_out = act_in, slope, act_out
+        self.need_hist(in_ring, d.hist)
+        op = OpDesc()
+        op.kind = OP_CONV
+        op.in_ring, op.out_ring, op.res_ring = in_ring, out_ring, res_ring
+        op.in_ch_off = op.out_ch_off = op.res_ch_off = 0
+        op.rate_out = rate_out
+        op.conv = d
+        op.w_off = self.blob.add(packed)
+        op.b_off = self.blob.add(bias) if bias is not None else -1
+        op.mean_off = op.scale_off = -1
+        op.ext_src = -1
+        op.impl = impl
+        self.ops.append(op)
+        self.op_names.append(name)
+        self.flops_per_frame += 2 * packed.numel() * rate_out
+        return op
+
+
+def _act_of(params, default="ELU"):
+    name = params.get("nonlinear_activation", default)
+    ap = params.get("nonlinear_activation_params", {}) or {}
+    if name == "ELU":
+        if float(ap.get("alpha", 1.0)) != 1.0:
+            raise NotImplementedError("ELU alpha != 1 is not supported")
+        return ACT_ELU, 0.0
+    if name == "LeakyReLU":
+        return ACT_LEAKY, float(ap.get("negative_slope", 0.01))
+    raise NotImplementedError(f"Activation {name} is not supported!")
+
+
+def _res_units(b, pre, x_ring, c, rate, act, slope, out_ring_of_last):
+    """3x CausalResidualUnit.inference; returns the ring holding the block output."""
+    for j in range(3):
+        h = b.scratch_ring(c, rate, "h")
+        b.conv(f"{pre}.res_units.{j}.conv1", x_ring, h, act, slope)
+        nxt = out_ring_of_last if j == 2 else b.ring(c, 0, rate)
+        b.conv(f"{pre}.res_units.{j}.conv2", h, nxt, act, slope, res_ring=x_ring)
+        x_ring = nxt
+    return x_ring
+
+
+def build_encoder(sd, p):
+    """Encoder.encode + Projector.encode (encoder.py:137-142, projector.py:52-54).  ext: [x, z]."""
+    specs = arch.autoencoder_encoder_convs(p)
+    b = Builder(sd, specs)
+    act, slope = _act_of(p)
+    hop = arch.hop_length(p)
+    in_ch = p.get("input_channels", 1)
+    activate = p.get("codec", "audiodec") == "activate_audiodec"
+    ch, ratios, strides = p.get("encode_channels", 32), p.get("enc_ratios", (2, 4, 8, 16)), p.get("enc_strides", (3, 4, 5, 5))
+    rx = b.ring(in_ch, 0, hop)
+    b.ring_write(rx, 0)
+    rate, c = hop, ch
+    cur = b.ring(c, 0, rate)
+    b.conv("encoder.conv", rx, cur)
+    for i, s in enumerate(strides):
+        pre = f"encoder.conv_blocks.{i}"
+        last = b.ring(c, 0, rate)
+        cur = _res_units(b, pre, cur, c, rate, act, slope, last)
+        c2, rate2 = ch * ratios[i], rate // s
+        nxt = b.ring(c2, 0, rate2)
+        b.conv(f"{pre}.conv", cur, nxt)
+        cur, c, rate = nxt, c2, rate2
+    z = b.ring(p.get("code_dim", 64), 0, rate, external=1)
+    # ActivateEncoder applies the activation to the encoder output (encoder.py:171-175)
+    b.conv("projector.project", cur, z, act if activate else ACT_NONE, slope)
+    return b
+
+
+def build_sym_decoder(sd, p):
+    """Decoder.decode / ActivateDecoder.decode (decoder.py:142-148, 203-214).  ext: [zq, y]."""
+    specs = arch.autoencoder_decoder_convs(p)
+    b = Builder(sd, specs)
+    act, slope = _act_of(p)
+    activate = p.get("codec", "audiodec") == "activate_audiodec"
+    ch, ratios, strides = p.get("decode_channels", 32), p.get("dec_ratios", (16, 8, 4, 2)), p.get("dec_strides", (5, 5, 4, 3))
+    rate = 1
+    rz = b.ring(p.get("code_dim", 64), 0, rate)
+    b.ring_write(rz, 0)
+    cur = b.ring(ch * ratios[0], 0, rate)
+    b.conv("decoder.conv1", rz, cur)
+    for i, s in enumerate(strides):
+        cout = ch * ratios[i + 1] if i < len(ratios) - 1 else ch
+        pre = f"decoder.conv_blocks.{i}.1" if activate else f"decoder.conv_blocks.{i}"
+        rate *= s
+        up = b.ring(cout, 0, rate)
+        b.conv(f"{pre}.conv", cur, up, act if activate else ACT_NONE, slope)
+        last = b.ring(cout, 0, rate)
+        cur = _res_units(b, pre, up, cout, rate, act, slope, last)
+    y = b.ring(p.get("output_channels", 1), 0, rate, external=1)
+    b.conv("decoder.conv2", cur, y, act if activate else ACT_NONE, slope, ACT_TANH if activate else ACT_NONE)
+    return b
+
+
+def build_hifigan(sd, p):
+    """HiFiGAN StreamGenerator.decode (HiFiGAN.py:268-296).  ext: [zq, y]."""
+    specs = arch.hifigan_convs(p)
+    b = Builder(sd, specs)
+    act, slope = _act_of(p, "LeakyReLU")
+    if not arch.hifigan_is_multigroup(p):
+        raise NotImplementedError("MultiReceptiveField vocoder (AudioDec v0) is not lowered yet")
+    groups = p.get("groups", 1)
+    ch = p.get("channels", 512)
+    n_layer = len(p["resblock_dilations"][0])
+    addl = p.get("use_additional_convs", True)
+    rate = 1
+    rz = b.ring(p["in_channels"], 0, rate)
+    norm = "mean" in sd
+    b.ring_write(rz, 0, sd["mean"] if norm else None, sd["scale"] if norm else None)
+    cur = b.ring(ch, 0, rate)
+    b.conv("input_conv", rz, cur)
+    c = ch
+    for i, s in enumerate(p["upsample_scales"]):
+        c = ch // (2 ** (i + 1))
+        rate *= s
+        x = b.ring(c, 0, rate)                                  # block input, un-repeated
+        b.conv(f"upsamples.{i}", cur, x, act, slope)            # upsamples[i].inference(act(c))
+        gs_in, gs_res = 0, 0                                    # first layer reads x.repeat(1, groups, 1)
+        for j in range(n_layer):
+            xt = b.ring(c * groups, 0, rate)
+            b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
+            if addl:
+                nx = b.ring(c * groups, 0, rate)
+                b.conv(f"blocks.{i}.convs2.{j}", xt, nx, act, slope, res_ring=x, res_group_stride=gs_res)
+            else:
+                raise NotImplementedError("use_additional_convs=False is not lowered yet")
+            x, gs_in, gs_res = nx, None, None
+        cur = b.ring(c, 0, rate)
+        b.conv(f"blocks.{i}.conv_out", x, cur)
+    y = b.ring(p.get("out_channels", 1), 0, rate, external=1)
+    # activation_output1 = nn.LeakyReLU() default slope 0.01 (HiFiGAN.py:116); tanh after (:117)
+    b.conv("output_conv", cur, y, ACT_LEAKY, 0.01, ACT_TANH)
+    return b
+
+
+# ---------------------------------------------------------------------------------------------
+# runtime wrapper
+# ---------------------------------------------------------------------------------------------
+class HipProgram:
+    """One model half on one HIP device for `batch` streams (C++ adk_program + arena + weights)."""
+
+    def __init__(self, builder, batch, max_frames, device):
+        self.dev = native.require_gpu(device)
+        self.lib = native.lib()
+        self.batch, self.max_frames = int(batch), int(max_frames)
+        self.op_names = list(builder.op_names)
+        self.flops_per_frame = builder.flops_per_frame
+        self.n_ops, self.n_rings = len(builder.ops), len(builder.rings)
+        off = 0
+        self.ring_rows, self.ring_meta = [], []
+        rings = (RingDesc * self.n_rings)()
+        for i, r in enumerate(builder.rings):
+            rows = r["hist"] + self.max_frames * r["rate"] if r["external"] < 0 else 0
+            rings[i].channels, rings[i].hist, rings[i].rate, rings[i].external = r["channels"], r["hist"], r["rate"], r["external"]
+            rings[i].arena_off = off if r["external"] < 0 else 0
+            self.ring_rows.append(rows)
+            self.ring_meta.append(dict(r, rows=rows, arena_off=off))
+            if r["external"] < 0:
+                off += self.batch * rows * r["channels"]
+                off += (-off) % 4
+        self.arena_floats = max(off, 4)
+        self.state_floats_per_stream = sum(r["hist"] * r["channels"] for r in builder.rings if r["external"] < 0)
+        self.weights = builder.blob.tensor().to(self.dev)
+        self.weight_floats = self.weights.numel()
+        self.arena = torch.zeros(self.arena_floats, dtype=torch.float32, device=self.dev)
+        ops = (OpDesc * self.n_ops)(*builder.ops)
+        self._ops = ops
+        h = C.c_void_p()
+        native.check(self.lib.adk_program_create(ops, self.n_ops, rings, self.n_rings, self.batch, self.max_frames,
+                                                 C.c_void_p(self.weights.data_ptr()), self.weight_floats,
+                                                 C.c_void_p(self.arena.data_ptr()), self.arena_floats, C.byref(h)),
+                     "adk_program_create")
+        self.h = h
+        self._ext = (C.c_void_p * 8)()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.adk_program_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def step(self, frames, ext):
+        for i, t in enumerate(ext):
+            self._ext[i] = t.data_ptr()
+        native.check(self.lib.adk_program_step(self.h, int(frames), self._ext, len(ext), native.current_stream(self.dev)),
+                     "adk_program_step")
+
+    def reset(self):
+        native.check(self.lib.adk_program_reset(self.h, native.current_stream(self.dev)), "adk_program_reset")
+
+    def cursors(self):
+        c = (C.c_int32 * self.n_rings)()
+        native.check(self.lib.adk_program_get_cursors(self.h, c, self.n_rings), "adk_program_get_cursors")
+        return list(c)
+
+    def set_cursors(self, cur):
+        c = (C.c_int32 * self.n_rings)(*cur)
+        native.check(self.lib.adk_program_set_cursors(self.h, c, self.n_rings), "adk_program_set_cursors")
+
+    def snapshot(self):
+        return self.arena.clone(), self.cursors()
+
+    def restore(self, snap):
+        self.arena.copy_(snap[0])
+        self.set_cursors(snap[1])
+
+    def set_profiling(self, on):
+        native.check(self.lib.adk_program_set_profiling(self.h, 1 if on else 0), "adk_program_set_profiling")
+
+    def last_op_ms(self):
+        ms = (C.c_float * self.n_ops)()
+        native.check(self.lib.adk_program_last_op_ms(self.h, ms, self.n_ops), "adk_program_last_op_ms")
+        return list(ms)

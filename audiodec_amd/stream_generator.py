@@ -1,0 +1,340 @@
+"""Host-side mirrors of the reference's streaming model objects.
+
+  AutoEncoderStreamGenerator  <->  models/autoencoder/AudioDec.py:166-256  StreamGenerator
+  HiFiGANStreamGenerator      <->  models/vocoder/HiFiGAN.py:222-305       StreamGenerator
+
+Same constructor keywords (the ``generator_params`` block of config.yml), same method names and
+argument meaning (``encode / quantize / lookup / decode / initial_encoder / initial_decoder /
+reset_buffer / load_state_dict / eval / to``), so ``utils/audiodec.py``-style callers work
+unchanged.  All arithmetic runs in libaudiodec_hip.so; these classes only own tensors and call it.
+
+Extension over the reference (which is batch-1 only, layers/conv_layer.py:144-146,
+layers/vq_module.py:148-161): ``configure(num_streams=B, max_frames=F)`` makes one object carry B
+independent streams; ``encode`` then takes ``(B, C, L)``, ``quantize`` returns ``(n_q, B, T)``,
+``lookup`` returns ``(B, T, 64)``, ``decode`` returns ``(B, out, T*hop)``.  With B = 1 all shapes are
+the reference's.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import arch, native, program
+
+# keyword defaults of the reference constructors (AudioDec.py:169-189, HiFiGAN.py:225-241)
+_AE_DEFAULTS = dict(
+    input_channels=1, output_channels=1, encode_channels=32, decode_channels=32, code_dim=64,
+    codebook_num=8, codebook_size=1024, bias=True, enc_ratios=(2, 4, 8, 16), dec_ratios=(16, 8, 4, 2),
+    enc_strides=(3, 4, 5, 5), dec_strides=(5, 5, 4, 3), mode="causal", codec="audiodec",
+    projector="conv1d", quantier="residual_vq", nonlinear_activation="ELU",
+    nonlinear_activation_params={}, use_weight_norm=False)
+_HG_DEFAULTS = dict(
+    in_channels=80, out_channels=1, channels=512, kernel_size=7, upsample_scales=(8, 8, 2, 2),
+    upsample_kernel_sizes=(16, 16, 4, 4), resblock_kernel_sizes=(3, 7, 11),
+    resblock_dilations=[(1, 3, 5), (1, 3, 5), (1, 3, 5)], groups=1, bias=True, use_additional_convs=True,
+    nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
+    use_weight_norm=True, stats=None)
+
+
+def _merge(defaults, kwargs, what):
+    unknown = set(kwargs) - set(defaults)
+    if unknown:
+        raise TypeError(f"{what}.__init__() got unexpected keyword argument(s) {sorted(unknown)}")
+    p = dict(defaults)
+    p.update(kwargs)
+    return p
+
+
+class _StreamBase:
+    def __init__(self):
+        self._sd = None
+        self._device = None
+        self.num_streams = 1
+        self.max_frames = 16
+
+    # ---- torch.nn.Module surface the reference's loader touches (bin/stream.py:59-61) ----
+    def eval(self):
+        return self
+
+    def to(self, device):
+        self._device = torch.device(device)
+        if self._device.type == "cuda" and self._device.index is None:
+            self._device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        return self
+
+    def configure(self, num_streams=1, max_frames=16):
+        """Number of independent streams carried by this object and the largest chunk (in hops)
+        one kernel sequence handles; longer calls are split, which is exact (chunked streaming ==
+        one-shot)."""
+        if num_streams < 1 or max_frames < 1:
+            raise ValueError("num_streams and max_frames must be >= 1")
+        if (num_streams, max_frames) != (self.num_streams, self.max_frames):
+            self.num_streams, self.max_frames = int(num_streams), int(max_frames)
+            self._drop_programs()
+        return self
+
+    def _expected_keys(self):
+        raise NotImplementedError
+
+    def load_state_dict(self, state_dict, strict=True):
+        exp = self._expected_keys()
+        missing = [k for k in exp if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in exp]
+        if strict and (missing or unexpected):
+            raise RuntimeError(
+                f"Error(s) in loading state_dict for {type(self).__name__}:\n"
+                f"\tMissing key(s) in state_dict: {missing[:8]}{'...' if len(missing) > 8 else ''}\n"
+                f"\tUnexpected key(s) in state_dict: {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+        for k, shape in exp.items():
+            if k in state_dict and tuple(state_dict[k].shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(state_dict[k].shape)} "
+                                   f"from checkpoint, the shape in current model is {tuple(shape)}.")
+        self._sd = {k: v.detach().to("cpu") for k, v in state_dict.items()}
+        for k, v in self._sd.items():
+            if k.endswith(".pad_buffer") and bool((v != 0).any()):
+                # rings hold the raw signal; a non-zero saved pad_buffer (post-activation values of a
+                # previously streamed model) cannot be adopted bit-exactly -- the warm-up overwrites it
+                import warnings
+                warnings.warn(f"{k}: non-zero pad_buffer in checkpoint is ignored (state is rebuilt by initial_*)")
+                break
+        self._drop_programs()
+        return self
+
+    def _dev(self):
+        if self._device is None:
+            raise native.NativeError("call .to('cuda:N') before running the model")
+        return native.require_gpu(self._device)
+
+    def _conv_keys(self, specs):
+        exp = {}
+        for s in specs:
+            if s.wn:
+                exp[s.wkey("weight_g")] = (s.wshape[0], 1, 1)
+                exp[s.wkey("weight_v")] = s.wshape
+            else:
+                exp[s.wkey("weight")] = s.wshape
+            if s.bias:
+                exp[s.wkey("bias")] = (s.cout,)
+            if s.kind != "conv1x1":
+                exp[f"{s.name}.pad_buffer"] = (1, s.cin, s.pad)
+        return exp
+
+    def _run_chunks(self, prog, src, rows_in_per_frame, ch_in, rows_out_per_frame, ch_out, frames):
+        """Drive `prog` over `frames` hops in chunks of <= max_frames.  src (B, frames*rows_in, ch_in)
+        contiguous; returns (B, frames*rows_out, ch_out)."""
+        B = self.num_streams
+        if frames <= self.max_frames:
+            out = torch.empty(B, frames * rows_out_per_frame, ch_out, dtype=torch.float32, device=src.device)
+            prog.step(frames, (src, out))
+            return out
+        out = torch.empty(B, frames * rows_out_per_frame, ch_out, dtype=torch.float32, device=src.device)
+        f0 = 0
+        while f0 < frames:
+            f = min(self.max_frames, frames - f0)
+            s = src[:, f0 * rows_in_per_frame:(f0 + f) * rows_in_per_frame].contiguous()
+            o = torch.empty(B, f * rows_out_per_frame, ch_out, dtype=torch.float32, device=src.device)
+            prog.step(f, (s, o))
+            out[:, f0 * rows_out_per_frame:(f0 + f) * rows_out_per_frame] = o
+            f0 += f
+        return out
+
+
+class AutoEncoderStreamGenerator(_StreamBase):
+    """AudioDec streaming generator (models/autoencoder/AudioDec.py:166-256)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.params = _merge(_AE_DEFAULTS, kwargs, "StreamGenerator")
+        p = self.params
+        if p["mode"] != "causal":      # check_mode (models/utils.py:13-15), asserted once here
+            raise AssertionError(f"Mode {p['mode']} does not support AudioDec Streamer!")
+        if p["codec"] not in ("audiodec", "activate_audiodec"):
+            raise NotImplementedError(f"Codec ({p['codec']}) is not supported!")
+        if p["projector"] != "conv1d":
+            raise NotImplementedError(f"Model ({p['projector']}) is not supported!")
+        if p["quantier"] != "residual_vq":
+            raise NotImplementedError(f"Model ({p['quantier']}) is not supported!")
+        if p["input_channels"] != 1 or p["output_channels"] != 1:
+            raise NotImplementedError("only mono (input_channels = output_channels = 1) is lowered")
+        self.input_channels = p["input_channels"]
+        self.hop = arch.hop_length(p)
+        self.n_q, self.dim, self.size = p["codebook_num"], p["code_dim"], p["codebook_size"]
+        self._enc = self._dec = None
+        self._embed = self._enorm = self._codebook = None
+
+    def _drop_programs(self):
+        self._enc = self._dec = None
+        self._embed = self._enorm = self._codebook = None
+
+    def _expected_keys(self):
+        p = self.params
+        exp = self._conv_keys(arch.autoencoder_encoder_convs(p) + arch.autoencoder_decoder_convs(p))
+        for i in range(self.n_q):
+            pre = f"quantizer.codebook.layers.{i}"
+            exp[f"{pre}.embed"] = (self.dim, self.size)
+            exp[f"{pre}.cluster_size"] = (self.size,)
+            exp[f"{pre}.embed_avg"] = (self.dim, self.size)
+        return exp
+
+    # ---- lazily built device state ----
+    def _encoder(self):
+        if self._enc is None:
+            self._enc = program.HipProgram(program.build_encoder(self._sd, self.params), self.num_streams,
+                                           self.max_frames, self._dev())
+        return self._enc
+
+    def _decoder(self):
+        if self._dec is None:
+            self._dec = program.HipProgram(program.build_sym_decoder(self._sd, self.params), self.num_streams,
+                                           self.max_frames, self._dev())
+        return self._dec
+
+    def _quantizer(self):
+        if self._embed is None:
+            dev = self._dev()
+            embeds = [self._sd[f"quantizer.codebook.layers.{i}.embed"].float() for i in range(self.n_q)]
+            # |E|^2 exactly as the reference forms it on the host (layers/vq_module.py:96)
+            enorm = torch.stack([e.pow(2).sum(0, keepdim=True)[0] for e in embeds])
+            self._embed = torch.stack(embeds).contiguous().to(dev)
+            self._enorm = enorm.contiguous().to(dev)
+        return self._embed, self._enorm
+
+    def initial(self):
+        """Quantizer.initial -> ResidualVQ.initial (layers/vq_module.py:151-157)."""
+        dev = self._dev()
+        cb = torch.stack([self._sd[f"quantizer.codebook.layers.{i}.embed"].float().transpose(0, 1) for i in range(self.n_q)])
+        self._codebook = cb.reshape(-1, cb.size(-1)).contiguous().to(dev)
+
+    # ---- reference API ----
+    def initial_encoder(self, receptive_length, device):
+        """AudioDec.py:216-221: warm every encoder-side state with `receptive_length` samples of silence."""
+        self.to(device)
+        self.initial()
+        frames = math.ceil(receptive_length / self.hop)
+        z = self.encode(torch.zeros(self.num_streams, self.input_channels, frames * self.hop, device=self._dev()))
+        idx = self.quantize(z[:1])
+        return self.lookup(idx)
+
+    def initial_decoder(self, zq):
+        self.decode(zq)                                        # AudioDec.py:224-225
+
+    def encode(self, x):
+        """(B, C, L) -> z (B', code_dim, ceil(L/hop))   (AudioDec.py:228-234)."""
+        dev = self._dev()
+        (batch, channel, length) = x.size()
+        if channel != self.input_channels:
+            x = x.reshape(-1, self.input_channels, length)
+        if x.shape[0] != self.num_streams:
+            raise ValueError(f"encode: got {x.shape[0]} streams, this object carries {self.num_streams} "
+                             "(configure(num_streams=...))")
+        x = x.to(device=dev, dtype=torch.float32)
+        frames = -(-length // self.hop)
+        if frames == 0:
+            return torch.empty(x.shape[0], self.dim, 0, device=dev)
+        if frames * self.hop != length:
+            # one-shot call on a ragged length (demoFile.py:58): zero-pad to a hop multiple; every output
+            # frame is exact by causality, only the state left behind differs
+            x = torch.nn.functional.pad(x, (0, frames * self.hop - length))
+        src = x.reshape(x.shape[0], frames * self.hop, 1) if x.is_contiguous() else x.contiguous().reshape(x.shape[0], -1, 1)
+        z = self._run_chunks(self._encoder(), src, self.hop, 1, 1, self.dim, frames)
+        return z.transpose(1, 2)
+
+    def quantize(self, z):
+        """z (B, code_dim, T) -> idx (n_q, T) for B == 1, (n_q, B, T) otherwise  (AudioDec.py:237-239)."""
+        dev = self._dev()
+        embed, enorm = self._quantizer()
+        B, D, T = z.shape
+        zt = z.to(device=dev, dtype=torch.float32).transpose(2, 1).contiguous()
+        idx = torch.empty(self.n_q, B * T, dtype=torch.int64, device=dev)
+        native.check(native.lib().adk_rvq_encode(
+            C.c_void_p(zt.data_ptr()), C.c_void_p(embed.data_ptr()), C.c_void_p(enorm.data_ptr()),
+            C.c_void_p(idx.data_ptr()), None, B * T, self.n_q, self.dim, self.size, native.current_stream(dev)),
+            "adk_rvq_encode")
+        idx = idx.reshape(self.n_q, B, T)
+        return idx.squeeze(1) if B == 1 else idx
+
+    def lookup(self, idx):
+        """idx (n_q, T) -> zq (1, T, code_dim); (n_q, B, T) -> (B, T, code_dim)  (AudioDec.py:242-243)."""
+        dev = self._dev()
+        if self._codebook is None:
+            self.initial()
+        idx = idx.to(device=dev, dtype=torch.int64)
+        if idx.dim() == 2:
+            idx = idx.unsqueeze(1)
+        n_q, B, T = idx.shape
+        idx = idx.contiguous()
+        zq = torch.empty(B, T, self.dim, dtype=torch.float32, device=dev)
+        native.check(native.lib().adk_rvq_lookup(
+            C.c_void_p(idx.data_ptr()), C.c_void_p(self._codebook.data_ptr()), C.c_void_p(zq.data_ptr()),
+            B * T, n_q, self.dim, self._codebook.shape[0], native.current_stream(dev)), "adk_rvq_lookup")
+        return zq
+
+    def decode(self, zq):
+        """zq (B, T, code_dim) -> y (B, out_channels, T*hop)  (AudioDec.py:246-247)."""
+        return _decode_common(self, self._decoder(), zq, self.dim, self.hop)
+
+    def reset_buffer(self):
+        """Zero every state ring (AudioDec.py:250-256)."""
+        for pr in (self._enc, self._dec):
+            if pr is not None:
+                pr.reset()
+
+
+def _decode_common(self, prog, zq, dim, hop):
+    dev = self._dev()
+    zq = zq.to(device=dev, dtype=torch.float32)
+    if zq.dim() != 3 or zq.shape[2] != dim:
+        raise ValueError(f"decode: expected (B, T, {dim}), got {tuple(zq.shape)}")
+    if zq.shape[0] == 1 and self.num_streams > 1:
+        zq = zq.expand(self.num_streams, -1, -1)
+    if zq.shape[0] != self.num_streams:
+        raise ValueError(f"decode: got {zq.shape[0]} streams, this object carries {self.num_streams}")
+    T = zq.shape[1]
+    if T == 0:
+        return torch.empty(zq.shape[0], 1, 0, device=dev)
+    y = self._run_chunks(prog, zq.contiguous(), 1, dim, hop, 1, T)
+    return y.reshape(zq.shape[0], 1, T * hop)
+
+
+class HiFiGANStreamGenerator(_StreamBase):
+    """HiFiGAN streaming generator (models/vocoder/HiFiGAN.py:222-305)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.params = _merge(_HG_DEFAULTS, kwargs, "StreamGenerator")
+        p = self.params
+        assert p["kernel_size"] % 2 == 1, "Kernel size must be odd number."            # HiFiGAN.py:61-63
+        assert len(p["upsample_scales"]) == len(p["upsample_kernel_sizes"])
+        assert len(p["resblock_dilations"]) == len(p["resblock_kernel_sizes"])
+        self.norm = p["stats"] is not None
+        self.hop = arch.hop_length(p)
+        self.dim = p["in_channels"]
+        self._dec = None
+
+    def _drop_programs(self):
+        self._dec = None
+
+    def _expected_keys(self):
+        exp = self._conv_keys(arch.hifigan_convs(self.params))
+        if self.norm:
+            exp["mean"] = (self.dim,)
+            exp["scale"] = (self.dim,)
+        return exp
+
+    def _decoder(self):
+        if self._dec is None:
+            self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params), self.num_streams,
+                                           self.max_frames, self._dev())
+        return self._dec
+
+    def initial_decoder(self, c):
+        self.decode(c)                                         # HiFiGAN.py:264-265
+
+    def decode(self, c):
+        """c (B, T, in_channels) -> (B, 1, T*hop): norm, input conv, upsample stack, output conv, tanh
+        (HiFiGAN.py:268-296)."""
+        return _decode_common(self, self._decoder(), c, self.dim, self.hop)
+
+    def reset_buffer(self):
+        if self._dec is not None:
+            self._dec.reset()

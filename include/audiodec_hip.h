@@ -1,0 +1,169 @@
+/*
+ * audiodec_hip.h -- C ABI of libaudiodec_hip.so: the AudioDec streaming hot path on MI355X (gfx950).
+ *
+ * The reference (facebookresearch/AudioDec) has no native layer: its hot path is PyTorch module
+ * methods.  This header is the FFI a maintainer would bind in their place (ctypes stub in
+ * INTEGRATION.md); every entry point names the reference method(s) it replaces.
+ *
+ * Conventions
+ *   - all data pointers are DEVICE pointers (fp32 unless stated); `stream` is a hipStream_t passed
+ *     as void*; calls enqueue work on that stream and return without synchronising
+ *   - return value: 0 = ADK_OK, negative = error (text via adk_last_error(), thread-local)
+ *   - no hidden device allocation in step/op calls; a handle may be used by one host thread at a
+ *     time, different handles concurrently (reference threading model: bin/stream.py:212-239)
+ *
+ * Data layout ("rings")
+ *   Every stateful conv input lives in a ring of channel-last rows: ring[b][r][c], r in [0,rows),
+ *   one row = one time step of `channels` floats.  The reference's per-layer `pad_buffer`
+ *   (layers/conv_layer.py:144-146,153-156) is the `hist` rows in front of the cursor; producers write
+ *   new rows at the cursor, consumers read [cursor-hist, cursor+T); nothing is ever copied or
+ *   shifted.  The ring stores the RAW (pre-activation) signal; the consumer's input activation
+ *   (ELU / LeakyReLU) is applied while the tile is staged on chip.
+ */
+#ifndef AUDIODEC_HIP_H
+#define AUDIODEC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADK_ABI_VERSION 1
+
+enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
+
+/* activations: layers/activation_function.py:18-22 -> torch.nn.{ELU,LeakyReLU,Tanh} */
+enum { ADK_ACT_NONE = 0, ADK_ACT_ELU = 1, ADK_ACT_LEAKY = 2, ADK_ACT_TANH = 3 };
+
+/* kernel selection for adk_causal_conv (ADK_IMPL_AUTO in production; others for tests/benchmarks) */
+enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 };
+
+const char* adk_last_error(void);
+int adk_abi_version(void);
+/* sticky device-side flags since the last call (bit 0: adk_rvq_lookup saw an out-of-range index,
+ * where F.embedding would raise); reading synchronises the device and clears them */
+int adk_debug_flags(int32_t* out);
+
+/* A view of one ring for one call. */
+typedef struct {
+    float*  base;      /* stream b starts at base + b * rows * channels                            */
+    int32_t rows;      /* ring length R                                                             */
+    int32_t channels;  /* row length C (all groups)                                                 */
+    int32_t cursor;    /* row of the first NEW time step of this call, 0 <= cursor < rows           */
+    int32_t ch_off;    /* first channel this op touches                                             */
+} adk_ring_view;
+
+/*
+ * One fused causal convolution:  replaces
+ *   CausalConv1d.inference            layers/conv_layer.py:153-156  (up == 1)
+ *   CausalConvTranspose1d.inference   layers/conv_layer.py:194-197  (up == stride s; polyphase form:
+ *       taps = 2, cout_g = s*Cout, weight row (r*Cout+co) = [W[:,co,s+r] | W[:,co,r]])
+ *   Conv1d1x1                         layers/conv_layer.py:28-32    (taps == 1, hist == 0)
+ * plus the element-wise ops the reference runs around them: input activation, bias, residual add
+ * (residual_unit.py:78-81, residual_block.py:99-105), output activation (HiFiGAN.py:294-296).
+ *
+ * For stream b, output step t in [0, t_out), GEMM row m in [0, groups*cout_g), g = m / cout_g:
+ *   acc = bias[m] + sum_{j<taps} sum_{ci<cin_g}
+ *           w[m][j*cin_g + ci] * act_in( in[b][(in.cursor - hist + t*stride + j*dilation) mod R][in.ch_off + g*in_group_stride + ci] )
+ *   acc += res[b][(res.cursor + t) mod R][res.ch_off + g*res_group_stride + (m mod cout_g)]     (if res.base)
+ *   out[b][(out.cursor + t*up + m / cout_real) mod R][out.ch_off + m mod cout_real] = act_out(acc)
+ */
+typedef struct {
+    int32_t cin_g, cout_g, groups;       /* per-group channels                                       */
+    int32_t taps, stride, dilation;      /* stride = input rows per output step                      */
+    int32_t hist;                        /* history rows in front of in.cursor: (taps-1)*dilation    */
+    int32_t up, cout_real;               /* up == 1: cout_real = groups*cout_g; transposed: see above */
+    int32_t in_group_stride;             /* 0 when all groups read the same channels (x.repeat, multi_fusion.py:134) */
+    int32_t res_group_stride;
+    int32_t act_in;  float act_in_slope;
+    int32_t act_out;
+    const float* w;                      /* [groups*cout_g][taps*cin_g], tap-major / channel-minor   */
+    const float* bias;                   /* [groups*cout_g] or NULL                                  */
+} adk_conv_desc;
+
+int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
+                    int32_t batch, int32_t t_out, int32_t impl, void* stream);
+
+/*
+ * Copy caller rows into a ring, optionally normalising: ring row = (src - mean) / scale.
+ * Replaces the torch.cat of new samples onto the state (conv_layer.py:154) for the first layer and
+ * HiFiGAN StreamGenerator.decode_norm (models/vocoder/HiFiGAN.py:276-279; true division).
+ * src is [batch][t][channels] contiguous.
+ */
+int adk_ring_write(const float* src, adk_ring_view ring, const float* mean, const float* scale,
+                   int32_t batch, int32_t t, void* stream);
+
+/*
+ * Residual VQ encode: replaces ResidualVQ.forward_index(flatten_idx=True) over
+ * VectorQuantize.forward_index (layers/vq_module.py:136-149, 90-104) for n_rows = B*T rows.
+ *   z      [n_rows][dim]            (channel-last latent, i.e. Quantizer.encode's z.transpose(2,1))
+ *   embed  [n_q][dim][size]         the reference's `embed` buffers (codes are columns)
+ *   enorm  [n_q][size]              embed.pow(2).sum(0) (vq_module.py:96), computed once at load
+ *   idx    [n_q][n_rows] int64      emitted index = code + size*stage (vq_module.py:145-146)
+ *   zq     [n_rows][dim] or NULL    sum of the straight-through quantised vectors (quantized_out)
+ * Arithmetic per stage follows the reference literally: dist = (|r|^2 - (2r).E) + |E|^2, argmax of
+ * -dist with lowest index on ties, q' = r + (q - r), r <- r - q'.
+ */
+int adk_rvq_encode(const float* z, const float* embed, const float* enorm, int64_t* idx, float* zq,
+                   int32_t n_rows, int32_t n_q, int32_t dim, int32_t size, void* stream);
+
+/*
+ * Residual VQ lookup: replaces ResidualVQ.lookup (layers/vq_module.py:159-161).
+ *   idx [n_q][n_rows] int64 (global indices 0..n_q*size-1), codebook [n_q*size][dim]
+ *   zq  [n_rows][dim] = sum over stages, stage 0 first
+ * An out-of-range index reads code 0 and raises bit 0 of adk_debug_flags().
+ */
+int adk_rvq_lookup(const int64_t* idx, const float* codebook, float* zq,
+                   int32_t n_rows, int32_t n_q, int32_t dim, int32_t n_codes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pipeline level: a "program" is the fixed launch sequence of one model half (encoder+projector,
+ * symmetric decoder, or HiFi-GAN vocoder) over B streams, with all rings in one caller-owned arena.
+ * Replaces StreamGenerator.encode / decode (models/autoencoder/AudioDec.py:228-247,
+ * models/vocoder/HiFiGAN.py:268-296) incl. the per-layer state hand-off.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct adk_program adk_program;
+
+typedef struct {
+    int32_t channels;    /* row length                                                               */
+    int32_t hist;        /* max history any consumer needs                                           */
+    int32_t rate;        /* rows per 'frame' (one hop of audio)                                      */
+    int32_t external;    /* -1: lives in the arena; >= 0: index into step()'s ext[] (rows = frames*rate, cursor 0) */
+    int64_t arena_off;   /* float offset of this ring in the arena (batch * rows * channels floats)  */
+} adk_ring_desc;
+
+enum { ADK_OP_CONV = 0, ADK_OP_RING_WRITE = 1 };
+
+typedef struct {
+    int32_t kind;                        /* ADK_OP_*                                                  */
+    int32_t in_ring, out_ring, res_ring; /* ring ids; res_ring = -1: none                             */
+    int32_t in_ch_off, out_ch_off, res_ch_off;
+    int32_t rate_out;                    /* output steps per frame (t_out = frames * rate_out)        */
+    adk_conv_desc conv;                  /* conv.w / conv.bias ignored; use w_off / b_off             */
+    int64_t w_off, b_off;                /* float offsets into the weight blob; b_off < 0: no bias    */
+    int64_t mean_off, scale_off;         /* ADK_OP_RING_WRITE: offsets of mean/scale, < 0: none       */
+    int32_t ext_src;                     /* ADK_OP_RING_WRITE: index into ext[] of the source rows    */
+    int32_t impl;                        /* ADK_IMPL_*                                                */
+} adk_op_desc;
+
+/* rows of ring i = hist + max_frames * rate (arena rings). */
+int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const adk_ring_desc* rings, int32_t n_rings,
+                       int32_t batch, int32_t max_frames, const float* weights, int64_t weights_floats,
+                       float* arena, int64_t arena_floats, adk_program** out);
+void adk_program_destroy(adk_program* p);
+/* one call = `frames` hops for every stream; ext[i] are the external buffers named by the descs */
+int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream);
+/* reset_buffer(): zero all history (AudioDec.py:250-256, HiFiGAN.py:298-305) */
+int adk_program_reset(adk_program* p, void* stream);
+/* ring cursors (n_rings int32), for snapshot / restore of a warmed-up state together with the arena */
+int adk_program_get_cursors(const adk_program* p, int32_t* cursors, int32_t n);
+int adk_program_set_cursors(adk_program* p, const int32_t* cursors, int32_t n);
+/* timing aid for bench.py: per-op HIP-event durations (ms) of the LAST step when enabled; synchronises */
+int adk_program_set_profiling(adk_program* p, int32_t enabled);
+int adk_program_last_op_ms(adk_program* p, float* ms, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIODEC_HIP_H */

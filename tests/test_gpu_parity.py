@@ -1,0 +1,248 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's committed outputs
+(tests/golden/*.npz) and against the CPU oracle on seeded inputs.
+
+Tolerances (north-star): decoded waveform <= 1e-4 max-abs; RVQ indices bit-exact -- a mismatch is
+reported with the reference's own top-2 distance margin so it can be told apart from a bug.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiodec_amd import configs, synth
+from oracle import audiodec_oracle as O
+import op_cases as C
+from test_oracle_golden import build_oracle, explain_flips, golden_chunks
+
+pytestmark = pytest.mark.gpu
+
+WAVE_TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    from audiodec_amd import native
+    native.lib()
+    return DEV
+
+
+@pytest.fixture(scope="module")
+def ckpt_root(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("audiodec_ckpt"))
+
+
+def load_audiodec(ckpt_root, model, seed, num_streams, max_frames):
+    from audiodec_amd.audiodec import AudioDec, assign_model
+    synth.write_model(ckpt_root, model, seed)
+    cwd = os.getcwd()
+    os.chdir(ckpt_root)          # the reference's paths are cwd-relative ('exp/...', 'stats/...')
+    try:
+        sr, enc_ckpt, dec_ckpt = assign_model(model)
+        ad = AudioDec(tx_device=DEV, rx_device=DEV, num_streams=num_streams, max_frames=max_frames)
+        ad.load_transmitter(enc_ckpt)
+        ad.load_receiver(enc_ckpt, dec_ckpt)
+    finally:
+        os.chdir(cwd)
+    return ad
+
+
+# ------------------------------------------------------------------------------------------------
+# layer level, against the reference's layer outputs (ops.npz) -- both kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl", ["direct", "mfma"])
+def test_causal_conv1d_matches_reference_layers(gpu, golden_dir, impl):
+    from audiodec_amd import layers, native
+    g = _load(golden_dir, "ops")
+    ran = 0
+    for n, (ci, co, k, s, d, gr, b, L1, L2) in enumerate(C.CONVS):
+        if impl == "mfma" and ((ci // gr) % 32 or co % 4):
+            continue
+        x1, x2, w, bias = C.conv_inputs(n)
+        m = layers.CausalConv1d(ci, co, k, s, d, gr, b, device=gpu, batch=1, max_len=256).load(w, bias)
+        m.impl = native.IMPL_MFMA if impl == "mfma" else native.IMPL_DIRECT
+        y1 = m.inference(x1).cpu().numpy()
+        y2 = m.inference(x2).cpu().numpy()
+        assert np.abs(y1 - g[f"conv{n}_y1"]).max() < 1e-5, (n, impl)
+        assert np.abs(y2 - g[f"conv{n}_y2"]).max() < 1e-5, (n, impl)
+        assert np.array_equal(m.pad_buffer.cpu().numpy(), g[f"conv{n}_pad"]), (n, impl)   # state is the raw input
+        ran += 1
+    assert ran >= 3
+
+
+@pytest.mark.parametrize("impl", ["direct", "mfma"])
+def test_causal_convtranspose1d_matches_reference_layers(gpu, golden_dir, impl):
+    from audiodec_amd import layers, native
+    g = _load(golden_dir, "ops")
+    for n, (ci, co, s, L1, L2) in enumerate(C.CONVTS):
+        x1, x2, w, bias = C.convt_inputs(n)
+        m = layers.CausalConvTranspose1d(ci, co, 2 * s, s, device=gpu, batch=1, max_len=64).load(w, bias)
+        m.impl = native.IMPL_MFMA if impl == "mfma" else native.IMPL_DIRECT
+        y1 = m.inference(x1).cpu().numpy()
+        y2 = m.inference(x2).cpu().numpy()
+        assert np.abs(y1 - g[f"convT{n}_y1"]).max() < 1e-5, (n, impl)
+        assert np.abs(y2 - g[f"convT{n}_y2"]).max() < 1e-5, (n, impl)
+        assert np.array_equal(m.pad_buffer.cpu().numpy(), g[f"convT{n}_pad"])
+
+
+def test_residual_vq_matches_reference_layers(gpu, golden_dir):
+    from audiodec_amd import layers
+    g = _load(golden_dir, "ops")
+    embeds, x = C.rvq_inputs()
+    rvq = layers.ResidualVQ(embeds, device=gpu)
+    q, idx = rvq.forward_index(x, flatten_idx=True)
+    assert np.array_equal(idx.cpu().numpy(), g["rvq_idx"])             # bit-exact, incl. the engineered tie
+    assert int(idx[0, 7]) == 123
+    assert np.abs(q.cpu().numpy() - g["rvq_q"]).max() < 1e-5
+    rvq.initial()
+    zq = rvq.lookup(idx)
+    assert np.abs(zq.cpu().numpy() - g["rvq_zq"]).max() < 1e-6
+    # un-flattened indices (ResidualVQ.forward_index default)
+    _, idx0 = rvq.forward_index(x)
+    assert np.array_equal(idx0.cpu().numpy(), g["rvq_idx"] - 1024 * np.arange(4)[:, None])
+
+
+# ------------------------------------------------------------------------------------------------
+# fused activation / grouped / residual paths against the oracle on random tensors
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,k,s,d,gr,act,B,L", [
+    (64, 64, 7, 1, 3, 1, "ELU", 3, 50), (96, 96, 11, 1, 5, 3, "LeakyReLU", 5, 20), (128, 256, 10, 5, 1, 1, None, 7, 25),
+    (512, 64, 3, 1, 1, 1, "ELU", 33, 1), (32, 96, 3, 1, 1, 1, "LeakyReLU", 2, 301)])
+def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(cin * 7 + k)
+    w = torch.randn(cout, cin // gr, k, generator=g) / (cin // gr * k) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    fn = {None: lambda v: v, "ELU": torch.nn.ELU(), "LeakyReLU": torch.nn.LeakyReLU(0.1)}[act]
+    pad = torch.zeros(B, cin, (k - 1) * d)
+    mods = []
+    for impl in (native.IMPL_DIRECT, native.IMPL_MFMA):
+        m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
+        m.set_activation(act, 0.1)
+        m.impl = impl
+        mods.append(m)
+    for step in range(3):                                 # ring wraps around during these steps
+        x = torch.randn(B, cin, L * s, generator=g)
+        ref, pad = O.causal_conv1d_inference(fn(x), fn(pad) if step == 0 else pad, w, bias, s, d, gr)
+        for m in mods:
+            y = m.inference(x).cpu()
+            assert float((y - ref).abs().max()) < 2e-5, (m.impl, step)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole path against the reference's outputs
+# ------------------------------------------------------------------------------------------------
+def run_hip(ad, audio, chunks):
+    n = audio.shape[0]
+    pos, z_l, i_l, q_l, y_l = 0, [], [], [], []
+    with torch.no_grad():
+        for c in chunks:
+            x = torch.from_numpy(audio[:, pos:pos + c])[:, None, :].to(DEV)
+            pos += c
+            z = ad.tx_encoder.encode(x)
+            idx = ad.tx_encoder.quantize(z)
+            zq = ad.rx_encoder.lookup(idx)
+            y = ad.decoder.decode(zq)
+            if n == 1:
+                idx = idx[:, None]
+            z_l.append(z.cpu()); i_l.append(idx.cpu()); q_l.append(zq.cpu()); y_l.append(y.cpu())
+    return (torch.cat(z_l, -1).numpy(), torch.cat(i_l, -1).numpy(), torch.cat(q_l, 1).numpy(), torch.cat(y_l, -1).numpy())
+
+
+@pytest.mark.parametrize("name,max_frames", [("vctk_sym_stream", 2), ("vctk_v1_stream", 4), ("libritts_sym_file", 16),
+                                             ("vctk_v2_stream", 2), ("vctk_activate_sym_stream", 2),
+                                             ("vctk_c16h320_sym_stream", 2)])
+def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames):
+    g = _load(golden_dir, name)
+    model, seed, n = str(g["model"]), int(g["seed"]), int(g["n_streams"])
+    chunks = golden_chunks(g)
+    audio = np.stack([synth.synth_audio(seed, s, sum(chunks)) for s in range(n)])
+    ad = load_audiodec(ckpt_root, model, seed, n, max_frames)
+    z, idx, zq, y = run_hip(ad, audio, chunks)
+    assert z.shape == g["z"].shape and y.shape == g["y"].shape and idx.shape == g["idx"].shape
+    assert np.abs(z - g["z"]).max() < WAVE_TOL
+    explain_flips(idx, g["idx"], g["margin"], name)
+    assert np.abs(zq - g["zq"]).max() < 1e-5
+    assert np.abs(y - g["y"]).max() < WAVE_TOL, f"max|dy| = {np.abs(y - g['y']).max():.3e}"
+
+
+@pytest.mark.parametrize("model,B,frames", [("vctk_v1", 16, [1, 1, 2, 1]), ("vctk_sym", 33, [1, 3])])
+def test_batched_streams_match_oracle(gpu, ckpt_root, model, B, frames):
+    """B streams in one object == the B-stream oracle (B independent reference instances)."""
+    seed = 4242
+    hop = 300
+    chunks = [f * hop for f in frames]
+    audio = np.stack([synth.synth_audio(seed, 100 + s, sum(chunks)) for s in range(B)])
+    ad = load_audiodec(ckpt_root, model, seed, B, 2)
+    z, idx, zq, y = run_hip(ad, audio, chunks)
+    tx, rx, dec = build_oracle(model, B, seed)
+    oz, oi, om, oy = [], [], [], []
+    pos = 0
+    with torch.no_grad():
+        for c in chunks:
+            x = torch.from_numpy(audio[:, pos:pos + c])[:, None, :]
+            pos += c
+            z_ = tx.encode(x)
+            i_, m_ = tx.quantize(z_, return_margin=True)
+            oy.append(dec.decode(rx.lookup(i_))); oz.append(z_); oi.append(i_); om.append(m_)
+    oz = torch.cat(oz, -1).numpy(); oi = torch.cat(oi, -1).numpy(); om = torch.cat(om, -1).numpy(); oy = torch.cat(oy, -1).numpy()
+    assert np.abs(z - oz).max() < WAVE_TOL
+    explain_flips(idx, oi, om, f"{model} B={B}")
+    assert np.abs(y - oy).max() < WAVE_TOL, f"max|dy| = {np.abs(y - oy).max():.3e}"
+
+
+def test_rvq_indices_bit_exact_on_reference_latents(gpu, golden_dir):
+    """Same z in -> same indices out: feed the REFERENCE's z (fixture) to the HIP quantiser."""
+    from audiodec_amd import layers
+    for name in ("libritts_sym_file", "vctk_v1_stream"):
+        g = _load(golden_dir, name)
+        _, enc_tag, _, _, _ = configs.alias(str(g["model"]))
+        sd = synth.synth_state_dict(enc_tag, int(g["seed"]))
+        embeds = [sd[f"quantizer.codebook.layers.{i}.embed"] for i in range(8)]
+        rvq = layers.ResidualVQ(embeds, device=gpu)
+        z = torch.from_numpy(g["z"]).transpose(2, 1).contiguous()          # (B, T, 64)
+        _, idx = rvq.forward_index(z, flatten_idx=True)
+        idx = idx.cpu().numpy()
+        if idx.ndim == 2:
+            idx = idx[:, None]
+        explain_flips(idx, g["idx"], g["margin"], name + " (reference z)")
+
+
+def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
+    """Streaming invariants on the HIP path: chunking is bit-exact, reset_buffer +
+    warm-up reproduces the initial state."""
+    seed, B, hop = 99, 3, 300
+    audio = np.stack([synth.synth_audio(seed, s, 8 * hop) for s in range(B)])
+    ad = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 3)
+    one = run_hip(ad, audio, [8 * hop])                    # split 3+3+2 internally
+    ad2 = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 3)
+    many = run_hip(ad2, audio, [hop, 2 * hop, hop, 3 * hop, hop])
+    assert np.array_equal(one[1], many[1])
+    assert np.array_equal(one[0], many[0]) and np.array_equal(one[3], many[3])
+    # reset + re-warm == fresh
+    ad2.tx_encoder.reset_buffer(); ad2.rx_encoder.reset_buffer(); ad2.decoder.reset_buffer()
+    ad2.tx_encoder.initial_encoder(8192, DEV)
+    ad2.decoder.initial_decoder(ad2.rx_encoder.initial_encoder(8192, DEV))
+    again = run_hip(ad2, audio, [8 * hop])
+    assert np.array_equal(one[1], again[1]) and np.array_equal(one[3], again[3])
+
+
+def test_error_behaviour(gpu, ckpt_root):
+    from audiodec_amd.audiodec import AudioDec, assign_model
+    from audiodec_amd import native
+    with pytest.raises(NotImplementedError):
+        assign_model("no_such_model")
+    ad = AudioDec(tx_device=DEV, rx_device=DEV)
+    with pytest.raises(AssertionError):
+        ad.load_transmitter("exp/does/not/exist.pkl")
+    with pytest.raises(native.NativeError):
+        AudioDec(tx_device="cpu", rx_device="cpu").load_transmitter(synth.write_model(ckpt_root, "vctk_sym", 1337)[1])
+    ad = load_audiodec(ckpt_root, "vctk_sym", 1337, 2, 2)
+    with pytest.raises(ValueError):
+        ad.tx_encoder.encode(torch.zeros(3, 1, 300, device=DEV))      # wrong stream count
