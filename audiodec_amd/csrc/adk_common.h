@@ -40,5 +40,7 @@ __device__ __forceinline__ float act_apply(float x, int act, float slope) {
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s);   // requires cin_g % 32 == 0 and 16-B alignment
 bool conv_mfma_supported(const ConvArgs& a);
+int conv_mfma_pick(const ConvArgs& a);
+const char* conv_mfma_cfg_name(int pick);
 
 }  // namespace adk

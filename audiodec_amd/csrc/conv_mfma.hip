@@ -217,32 +217,39 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
 
 // Tile choice: the largest tile that still yields >= 2 workgroups per CU (256 CUs); M padding
 // waste is avoided by matching BM to cout_g.  ADK_CONV_CFG=<0..5> forces a config (tuning aid).
+static const Cfg kCfgs[6] = {{128, 128}, {64, 128}, {32, 256}, {64, 64}, {128, 32}, {32, 128}};
+
+int conv_mfma_pick(const ConvArgs& a) {
+    static const int forced = [] { const char* e = getenv("ADK_CONV_CFG"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && forced <= 5) return forced;
+    auto tiles = [&](const Cfg& c) {
+        return (long long)((a.cout_g + c.bm - 1) / c.bm) * a.groups * ((a.n_total + c.bn - 1) / c.bn);
+    };
+    auto waste_ok = [&](const Cfg& c) {     // <= 1/3 of the M tile may be padding
+        const int mt = (a.cout_g + c.bm - 1) / c.bm;
+        return 3 * (mt * c.bm - a.cout_g) <= mt * c.bm;
+    };
+    const int order[6] = {0, 1, 2, 3, 5, 4};
+    long long best_tiles = -1; int best = 3;
+    for (int i = 0; i < 6; ++i) {
+        const Cfg& c = kCfgs[order[i]];
+        if (!waste_ok(c)) continue;
+        const long long t = tiles(c);
+        if (t >= 512) return order[i];
+        if (t > best_tiles) { best_tiles = t; best = order[i]; }
+    }
+    return best;
+}
+
+const char* conv_mfma_cfg_name(int pick) {
+    static const char* names[6] = {"conv_mfma<128,128>", "conv_mfma<64,128>", "conv_mfma<32,256>",
+                                   "conv_mfma<64,64>", "conv_mfma<128,32>", "conv_mfma<32,128>"};
+    return names[pick];
+}
+
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
     if (a.n_total == 0) return ADK_OK;
-    static const int forced = [] { const char* e = getenv("ADK_CONV_CFG"); return e ? atoi(e) : -1; }();
-    static const Cfg cfgs[6] = {{128, 128}, {64, 128}, {32, 256}, {64, 64}, {128, 32}, {32, 128}};
-    int pick = forced;
-    if (pick < 0 || pick > 5) {
-        auto tiles = [&](const Cfg& c) {
-            return (long long)((a.cout_g + c.bm - 1) / c.bm) * a.groups * ((a.n_total + c.bn - 1) / c.bn);
-        };
-        auto waste_ok = [&](const Cfg& c) {     // <= 1/3 of the M tile may be padding
-            const int mt = (a.cout_g + c.bm - 1) / c.bm;
-            return 3 * (mt * c.bm - a.cout_g) <= mt * c.bm;
-        };
-        const int order[6] = {0, 1, 2, 3, 5, 4};
-        pick = -1;
-        long long best_tiles = -1; int best = 3;
-        for (int i = 0; i < 6; ++i) {
-            const Cfg& c = cfgs[order[i]];
-            if (!waste_ok(c)) continue;
-            const long long t = tiles(c);
-            if (t >= 512) { pick = order[i]; break; }
-            if (t > best_tiles) { best_tiles = t; best = order[i]; }
-        }
-        if (pick < 0) pick = best;
-    }
-    switch (pick) {
+    switch (conv_mfma_pick(a)) {
         case 0: return launch_cfg<128, 128, 2, 2>(a, s);
         case 1: return launch_cfg<64, 128, 2, 2>(a, s);
         case 2: return launch_cfg<32, 256, 1, 4>(a, s);

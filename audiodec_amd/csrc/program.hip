@@ -5,6 +5,7 @@
 #include "adk_common.h"
 #include <vector>
 #include <cstring>
+#include <cstdio>
 
 namespace adk {
 
@@ -210,6 +211,31 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
     for (size_t i = 0; i < p->rings.size(); ++i)
         if (p->rings[i].external < 0)
             p->cursor[i] = (int32_t)(((long long)p->cursor[i] + (long long)frames * p->rings[i].rate) % p->rows[i]);
+    return ADK_OK;
+}
+
+extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frames, char* buf, int32_t n) {
+    if (!p || !buf || n <= 0 || op < 0 || op >= (int)p->ops.size()) return fail(ADK_ERR_ARG, "program_describe_op: bad arguments");
+    const adk_op_desc& o = p->ops[op];
+    std::string name = "ring_write";
+    if (o.kind == ADK_OP_CONV) {
+        adk_conv_desc d = o.conv;
+        d.w = p->weights + o.w_off;
+        d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
+        alignas(16) static float aligned_dummy[4];   // stand-in for the (16-byte aligned) external buffers:
+        void* ext[8];                                // only geometry/alignment is inspected, nothing is launched
+        for (auto& e : ext) e = aligned_dummy;
+        adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
+        adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
+        adk_ring_view res; memset(&res, 0, sizeof(res));
+        if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
+        ConvArgs a;
+        int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+        if (rc != ADK_OK) return rc;
+        const bool mf = o.impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (o.impl == ADK_IMPL_MFMA || a.groups * a.cout_g >= 32);
+        name = mf ? conv_mfma_cfg_name(conv_mfma_pick(a)) : (a.groups * a.cout_g == 1 ? "conv_cout1" : "conv_direct");
+    }
+    snprintf(buf, n, "%s", name.c_str());
     return ADK_OK;
 }
 

@@ -346,6 +346,11 @@ class HipProgram:
         self.arena.copy_(snap[0])
         self.set_cursors(snap[1])
 
+    def describe_op(self, op, frames):
+        buf = C.create_string_buffer(64)
+        native.check(self.lib.adk_program_describe_op(self.h, op, frames, buf, 64), "adk_program_describe_op")
+        return buf.value.decode()
+
     def set_profiling(self, on):
         native.check(self.lib.adk_program_set_profiling(self.h, 1 if on else 0), "adk_program_set_profiling")
 

@@ -1,0 +1,87 @@
+"""Multi-GPU: independent streams are the shard.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm).  Stream k of a job lives
+on rank ``k // streams_per_rank``; every rank holds a full weight replica and its own state
+arena, so the steady state needs NO collective.  RCCL is used only for
+  * ``broadcast_state_dict``: rank 0 loads (or synthesises) a checkpoint, everyone receives the
+    same bits (one flat fp32 broadcast per state dict),
+  * ``gather_codes`` / ``gather_rows``: optional egress of emitted indices / waveforms to rank 0,
+  * the timing barrier / max-reduction in bench.py.
+The same functions run on CPU tensors over gloo (tests/test_shard_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def stream_range(n_streams, rank=None, world_size=None):
+    """Contiguous block of global stream ids owned by `rank` (sizes differ by at most one)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    base, extra = divmod(n_streams, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def owner_of(stream, n_streams, world_size):
+    for r in range(world_size):
+        lo, hi = stream_range(n_streams, r, world_size)
+        if lo <= stream < hi:
+            return r
+    raise IndexError(stream)
+
+
+def broadcast_state_dict(sd, src=0, device=None):
+    """Make every rank hold rank `src`'s tensors.  Non-src ranks pass a dict with the same keys/shapes
+    (e.g. freshly constructed) or None together with `template` semantics handled by the caller."""
+    rank, w = world()
+    if w == 1:
+        return sd
+    keys = sorted(sd.keys())
+    dev = device if device is not None else "cpu"
+    flat = torch.cat([sd[k].detach().reshape(-1).to(torch.float32) for k in keys]).to(dev)
+    dist.broadcast(flat, src=src)
+    flat = flat.cpu()
+    out, off = {}, 0
+    for k in keys:
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].reshape(sd[k].shape).to(sd[k].dtype)
+        off += n
+    return out
+
+
+def gather_rows(local, dst=0):
+    """Concatenate per-rank tensors along dim 0 on `dst` (ranks may own different stream counts)."""
+    rank, w = world()
+    if w == 1:
+        return local
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(w)]
+    dist.all_gather(sizes, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
+    mx = int(max(int(s) for s in sizes))
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(bufs, pad)
+    if rank != dst:
+        return None
+    return torch.cat([b[:int(s)] for b, s in zip(bufs, sizes)], 0)
+
+
+def gather_codes(idx, dst=0):
+    """idx (n_q, B_local, T) -> (n_q, B_total, T) on `dst`."""
+    g = gather_rows(idx.transpose(0, 1).contiguous(), dst)
+    return None if g is None else g.transpose(0, 1).contiguous()
+
+
+def max_over_ranks(value, device):
+    rank, w = world()
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if w > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

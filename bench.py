@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- the AudioDec streaming hot path on MI355X.
+
+Workload at any N (weak scaling): per GPU 256 concurrent 48 kHz streams of the `vctk_v1` pipeline
+(symAD encoder+projector -> 8-stage RVQ -> codebook lookup -> AudioDec-v1 HiFi-GAN vocoder), one
+hop (300 samples = 1 frame) per stream per step, streaming state carried across steps
+(BASELINE.json config 5 per-GPU share; 8 GPUs = its 2048 streams).  One step = one pass of the
+hot path over one batch of synthetic audio already resident in HBM.
+
+Prints ONE JSON line (rank 0).  value = frames/s for the whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODEL = "vctk_v1"
+SEED = 1337
+HOP = 300
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_audiodec(root, device, streams, max_frames, sd_bcast=False):
+    from audiodec_amd import synth
+    from audiodec_amd.audiodec import AudioDec, assign_model
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        sr, enc_ckpt, dec_ckpt = assign_model(MODEL)
+        ad = AudioDec(tx_device=device, rx_device=device, num_streams=streams, max_frames=max_frames)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            ad.load_transmitter(enc_ckpt)
+            ad.load_receiver(enc_ckpt, dec_ckpt)
+    finally:
+        os.chdir(cwd)
+    return ad
+
+
+def step(ad, x):
+    z = ad.tx_encoder.encode(x)
+    idx = ad.tx_encoder.quantize(z)
+    zq = ad.rx_encoder.lookup(idx)
+    return ad.decoder.decode(zq)
+
+
+def op_profile(ad, xs, streams, n_steps):
+    """Per-op HIP-event durations (events recorded on the launch stream by the C++ runner)."""
+    progs = {"encoder": ad.tx_encoder._encoder(), "decoder": ad.decoder._decoder()}
+    for p in progs.values():
+        p.set_profiling(True)
+    acc = {k: np.zeros(p.n_ops) for k, p in progs.items()}
+    for i in range(n_steps):
+        step(ad, xs[i % len(xs)])
+        for k, p in progs.items():
+            acc[k] += np.asarray(p.last_op_ms())
+    for p in progs.values():
+        p.set_profiling(False)
+    rows = []
+    for k, p in progs.items():
+        for i in range(p.n_ops):
+            op = p._ops[i]
+            flops = 0.0
+            if op.kind == 0:
+                c = op.conv
+                flops = 2.0 * c.groups * c.cout_g * c.taps * c.cin_g * op.rate_out * streams
+            rows.append(dict(prog=k, name=p.op_names[i], kernel=p.describe_op(i, 1), ms=acc[k][i] / n_steps, flops=flops, op=op))
+    return rows
+
+
+def roofline_from(rows, streams):
+    by = {}
+    for r in rows:
+        d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
+        d["ms"] += r["ms"]; d["flops"] += r["flops"]; d["launches"] += 1
+    dom = max(by, key=lambda k: by[k]["ms"])
+    d = by[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+            "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3)}
+    # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
+    ct = [r for r in rows if r["name"] == "upsamples.3"]
+    roof_ct = None
+    if ct:
+        r = ct[0]; c = r["op"].conv
+        t_in = r["op"].rate_out
+        cin, cout, s = c.cin_g, c.cout_real, c.up
+        bytes_alg = 4.0 * (cin * (t_in + 1) + cout * t_in * s) * streams + 4.0 * cin * cout * 2 * s
+        gbs = bytes_alg / (r["ms"] * 1e-3) / 1e9
+        roof_ct = {"kernel": r["kernel"] + " upsamples.3 (LeakyReLU+ConvTranspose1d 64->32 s3 +bias)", "bound": "hbm",
+                   "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "traffic": None, "avg_launch_us": round(1e3 * r["ms"], 2), "bytes_per_launch": bytes_alg,
+                   "fp32_tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)}
+    kernels = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0} for k, v in by.items()}
+    return roof, roof_ct, kernels
+
+
+def cpu_baseline(budget_s=12.0, threads=4):
+    """The CPU port (oracle = the reference's own ATen CPU kernels, minus its inspect.stack() cost)
+    streaming ONE stream of the same pipeline frame by frame on the host cores."""
+    from audiodec_amd import synth, configs
+    from oracle import audiodec_oracle as O
+    torch.set_num_threads(threads)
+    _, enc_tag, _, dec_tag, _ = configs.alias(MODEL)
+    mt_d, _, pd = configs.experiment(dec_tag)
+    _, _, pe = configs.experiment(enc_tag)
+    tx = O.AutoEncoderOracle(synth.synth_state_dict(enc_tag, SEED), pe, 1)
+    zq0 = tx.initial_encoder(8192)
+    dec = O.build_decoder_oracle(synth.synth_state_dict(dec_tag, SEED), mt_d, pd, 1)
+    dec.initial_decoder(zq0)
+    x = torch.from_numpy(synth.synth_audio(SEED, 0, 64 * HOP))[None, None, :]
+    n, t0 = 0, None
+    with torch.no_grad():
+        for i in range(100000):
+            if i == 3:
+                t0 = time.perf_counter()           # 3 warm-up frames
+            f = i % 64
+            dec.decode(tx.lookup(tx.quantize(tx.encode(x[:, :, f * HOP:(f + 1) * HOP]))))
+            if t0 is not None:
+                n += 1
+                if time.perf_counter() - t0 > budget_s:
+                    break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} consecutive single-frame (300-sample) encode+RVQ+lookup+v1-decode steps of ONE stream "
+                      f"(the reference is batch-1), {dt:.1f} s, torch.set_num_threads({threads}) of {os.cpu_count()} host cpus",
+            "ms_per_frame": round(1e3 * dt / n, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-profile", action="store_true")
+    ap.add_argument("--dump-ops", type=str, default=None, help="write the per-op HIP-event table (CSV) here")
+    args = ap.parse_args()
+
+    import __graft_entry__
+    __graft_entry__.build()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from audiodec_amd import synth, shard, configs
+    B = args.streams
+    # rank 0 synthesises the checkpoints; the bits reach the other ranks through RCCL (shard.py)
+    _, enc_tag, _, dec_tag, _ = configs.alias(MODEL)
+    sds = {}
+    for tag in (enc_tag, dec_tag):
+        sd = synth.synth_state_dict(tag, SEED if rank == 0 else SEED + 1)
+        sds[tag] = shard.broadcast_state_dict(sd, src=0, device=dev)
+    tmp = tempfile.TemporaryDirectory()
+    sr, _, tx_steps, _, rx_steps = configs.alias(MODEL)
+    synth.write_experiment(tmp.name, enc_tag, tx_steps, SEED, sd=sds[enc_tag])
+    synth.write_experiment(tmp.name, dec_tag, rx_steps, SEED, sd=sds[dec_tag])
+    ad = build_audiodec(tmp.name, dev, B, 1)
+
+    lo, hi = rank * B, (rank + 1) * B            # global stream ids of this rank
+    n_buf = 8
+    xs = [torch.from_numpy(np.stack([synth.synth_audio(SEED + j, s, HOP) for s in range(lo, hi)]))[:, None, :].to(dev)
+          for j in range(n_buf)]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(ad, xs[i % n_buf])
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            y = step(ad, xs[i % n_buf])
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, dev)
+    frames = world * B * args.steps
+    ms_per_step = 1e3 * elapsed / args.steps
+    out = {
+        "metric": "48 kHz hop-300 frames/s/GPU + per-frame encode+decode latency (ms)",
+        "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{MODEL} full pipeline (symAD encoder+projector -> 8x1024 RVQ -> lookup -> AudioDec-v1 "
+                               "HiFi-GAN vocoder), 48 kHz hop 300, streaming, 1 frame per stream per step "
+                               "(BASELINE.json config 5 per-GPU share)",
+                   "streams_per_gpu": B, "streams_total": world * B, "frames_per_step_per_stream": 1,
+                   "sample_rate": 48000, "hop": HOP, "weights": "seeded synthetic (audiodec_amd/synth.py), fp32"},
+        "frames_per_s_per_gpu": round(frames / elapsed / world, 1),
+        "latency_ms": {"encode_decode_step_at_batch": round(ms_per_step, 4)},
+        "realtime_streams_supported_per_gpu": int(frames / elapsed / world / 160.0),
+    }
+
+    if rank == 0 and world == 1:
+        with torch.no_grad():
+            if not args.no_op_profile:
+                rows = op_profile(ad, xs, B, 10)
+                if args.dump_ops:
+                    with open(args.dump_ops, "w") as f:
+                        f.write("prog,op,kernel,cin_g,cout_g,groups,taps,dil,t_out_per_stream,us,gflop,tflops\n")
+                        for r in rows:
+                            c = r["op"].conv
+                            f.write(f"{r['prog']},{r['name']},{r['kernel']},{c.cin_g},{c.cout_g},{c.groups},{c.taps},{c.dilation},"
+                                    f"{r['op'].rate_out},{1e3 * r['ms']:.2f},{r['flops'] / 1e9:.3f},"
+                                    f"{(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0:.2f}\n")
+                roof, roof_ct, kernels = roofline_from(rows, B)
+                out["roofline"] = roof
+                out["roofline_convtr"] = roof_ct
+                out["kernels"] = kernels
+                enc_ms = sum(r["ms"] for r in rows if r["prog"] == "encoder")
+                dec_ms = sum(r["ms"] for r in rows if r["prog"] == "decoder")
+                out["latency_ms"]["encoder_kernels_at_batch"] = round(enc_ms, 4)
+                out["latency_ms"]["decoder_kernels_at_batch"] = round(dec_ms, 4)
+                tot_flops = sum(r["flops"] for r in rows)
+                out["pipeline_tflops"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12, 2)
+            # single-stream latency: device-complete time of one encode+decode step, B = 1
+            ad1 = build_audiodec(tmp.name, dev, 1, 1)
+            x1 = xs[0][:1].contiguous()
+            for _ in range(10):
+                step(ad1, x1)
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(50):
+                t1 = time.perf_counter()
+                step(ad1, x1)
+                torch.cuda.synchronize()
+                lat.append(1e3 * (time.perf_counter() - t1))
+            out["latency_ms"]["encode_decode_single_stream_median"] = round(float(np.median(lat)), 4)
+            out["latency_ms"]["encode_decode_single_stream_min"] = round(float(np.min(lat)), 4)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

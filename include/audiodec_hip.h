@@ -159,6 +159,8 @@ int adk_program_reset(adk_program* p, void* stream);
 /* ring cursors (n_rings int32), for snapshot / restore of a warmed-up state together with the arena */
 int adk_program_get_cursors(const adk_program* p, int32_t* cursors, int32_t n);
 int adk_program_set_cursors(adk_program* p, const int32_t* cursors, int32_t n);
+/* name of the kernel op `op` runs for a `frames`-hop step (e.g. "conv_mfma<64,64>"), for profiles */
+int adk_program_describe_op(adk_program* p, int32_t op, int32_t frames, char* buf, int32_t n);
 /* timing aid for bench.py: per-op HIP-event durations (ms) of the LAST step when enabled; synchronises */
 int adk_program_set_profiling(adk_program* p, int32_t enabled);
 int adk_program_last_op_ms(adk_program* p, float* ms, int32_t n);
