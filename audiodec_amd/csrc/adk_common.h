@@ -27,6 +27,7 @@ struct ConvArgs {
     int act_in, act_out; float slope;
     int batch, t_out, n_total;      // n_total = batch * t_out GEMM columns
     int ktot;                       // taps * cin_g
+    int dbg;                        // ablation bits (tuning only): 1 no global loads in loop, 2 no MFMA, 4 no lstore/barrier
 };
 
 __device__ __forceinline__ float act_apply(float x, int act, float slope) {
@@ -42,5 +43,6 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s);   // requires cin_g % 32
 bool conv_mfma_supported(const ConvArgs& a);
 int conv_mfma_pick(const ConvArgs& a);
 const char* conv_mfma_cfg_name(int pick);
+void conv_mfma_force_cfg(int cfg);
 
 }  // namespace adk

@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int l31 = lane & 31, lh = lane >> 5;
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
-        if (kc + 1 < nchunks) gload(kc + 1);          // global loads in flight under the MFMAs
+        if (kc + 1 < nchunks && !(a.dbg & 1)) gload(kc + 1);          // global loads in flight under the MFMAs
         const float* Ab = As + cur * BM * LDK + (wm * WM + l31) * LDK + 4 * lh;
         const float* Bb = Bs + cur * BN * LDK + (wn * WN + l31) * LDK + 4 * lh;
+        if (!(a.dbg & 2))
 #pragma unroll
         for (int q = 0; q < KC / 8; ++q) {
             float4 av[MI], bv[NJ];
@@ -140,8 +141,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        if (!(a.dbg & 4)) {
         if (kc + 1 < nchunks) lstore(cur ^ 1);
         __syncthreads();
+        }
     }
 
     // epilogue: lane holds column n = ..+(lane&31), rows 8*qd + 4*(lane>>5) + {0..3} of each 32x32 tile
@@ -219,26 +222,20 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
 // waste is avoided by matching BM to cout_g.  ADK_CONV_CFG=<0..5> forces a config (tuning aid).
 static const Cfg kCfgs[6] = {{128, 128}, {64, 128}, {32, 256}, {64, 64}, {128, 32}, {32, 128}};
 
+static int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
+
+void conv_mfma_force_cfg(int cfg) { g_forced_cfg = cfg; }
+
 int conv_mfma_pick(const ConvArgs& a) {
-    static const int forced = [] { const char* e = getenv("ADK_CONV_CFG"); return e ? atoi(e) : -1; }();
+    if (g_forced_cfg == -2) { const char* e = getenv("ADK_CONV_CFG"); g_forced_cfg = e ? atoi(e) : -1; }
+    const int forced = g_forced_cfg;
     if (forced >= 0 && forced <= 5) return forced;
-    auto tiles = [&](const Cfg& c) {
-        return (long long)((a.cout_g + c.bm - 1) / c.bm) * a.groups * ((a.n_total + c.bn - 1) / c.bn);
-    };
-    auto waste_ok = [&](const Cfg& c) {     // <= 1/3 of the M tile may be padding
-        const int mt = (a.cout_g + c.bm - 1) / c.bm;
-        return 3 * (mt * c.bm - a.cout_g) <= mt * c.bm;
-    };
-    const int order[6] = {0, 1, 2, 3, 5, 4};
-    long long best_tiles = -1; int best = 3;
-    for (int i = 0; i < 6; ++i) {
-        const Cfg& c = kCfgs[order[i]];
-        if (!waste_ok(c)) continue;
-        const long long t = tiles(c);
-        if (t >= 512) return order[i];
-        if (t > best_tiles) { best_tiles = t; best = order[i]; }
-    }
-    return best;
+    // Measured on MI355X (profiles/r1_cfg_sweep.md): with one barrier per 32-deep K chunk the 32x32
+    // wave tile (one accumulator per wave, >= 3 workgroups per CU) beats the larger tiles on every
+    // layer of the path, so pick among the three 4-wave arrangements of it by the M extent.
+    if (a.cout_g % 128 == 0) return 4;      // 128 x 32
+    if (a.cout_g % 64 == 0) return 3;       // 64 x 64
+    return 5;                               // 32 x 128
 }
 
 const char* conv_mfma_cfg_name(int pick) {
@@ -247,8 +244,10 @@ const char* conv_mfma_cfg_name(int pick) {
     return names[pick];
 }
 
-int launch_conv_mfma(const ConvArgs& a, hipStream_t s) {
-    if (a.n_total == 0) return ADK_OK;
+int launch_conv_mfma(const ConvArgs& a0, hipStream_t s) {
+    if (a0.n_total == 0) return ADK_OK;
+    ConvArgs a = a0;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ADK_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     switch (conv_mfma_pick(a)) {
         case 0: return launch_cfg<128, 128, 2, 2>(a, s);
         case 1: return launch_cfg<64, 128, 2, 2>(a, s);

@@ -52,6 +52,7 @@ static int build_args(const adk_conv_desc& d, const adk_ring_view& in, const adk
     a.cin_g = d.cin_g; a.cout_g = d.cout_g; a.groups = d.groups; a.taps = d.taps; a.stride = d.stride;
     a.dilation = d.dilation; a.up = d.up; a.cout_real = d.cout_real;
     a.act_in = d.act_in; a.act_out = d.act_out; a.slope = d.act_in_slope;
+    a.dbg = 0;
     a.batch = batch; a.t_out = t_out; a.n_total = batch * t_out; a.ktot = d.taps * d.cin_g;
     return ADK_OK;
 }
@@ -74,6 +75,7 @@ using namespace adk;
 
 extern "C" const char* adk_last_error(void) { return g_err.c_str(); }
 extern "C" int adk_abi_version(void) { return ADK_ABI_VERSION; }
+extern "C" int adk_set_conv_cfg(int32_t cfg) { conv_mfma_force_cfg(cfg); return ADK_OK; }
 
 extern "C" int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
                                int32_t batch, int32_t t_out, int32_t impl, void* stream) {

@@ -17,24 +17,28 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float v2, int i2)
     if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
 }
 
-// One workgroup = RB rows (b,t) x all codes; 4 consecutive codes per thread per 1024-code slab, so
+// One workgroup = RB rows (b,t) x all codes: 1024 threads, one code per thread per 1024-code slab, so
 // the codebook (dim-major, codes contiguous: the reference's `embed` layout) is read with coalesced
-// float4 loads and every loaded value is reused for RB rows.  The 8 stages stay inside one launch
-// because stage i+1 needs r - q'_i.  Wave-level (value,index) reduction by DPP/shuffle, then LDS
-// across the 4 waves.
+// 256-byte wave loads and every loaded value is reused for RB rows; 16 waves per workgroup keep the
+// L2 latency of the 64 dependent-free loads per stage hidden.  The 8 stages stay inside one launch
+// because stage i+1 needs r - q'_i.  Wave-level (value,index) reduction by shuffles, then LDS
+// across the 16 waves.
+constexpr int RVQ_THREADS = 1024;
+constexpr int RVQ_WAVES = RVQ_THREADS / 64;
+
 template <int RB>
-__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ z, const float* __restrict__ embed,
-                                                         const float* __restrict__ enorm, long long* __restrict__ idx,
-                                                         float* __restrict__ zq, int n_rows, int n_q, int dim, int size) {
+__global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __restrict__ z, const float* __restrict__ embed,
+                                                                 const float* __restrict__ enorm, long long* __restrict__ idx,
+                                                                 float* __restrict__ zq, int n_rows, int n_q, int dim, int size) {
     __shared__ float r_sh[RB][RVQ_DIM_MAX];
     __shared__ float q_sh[RB][RVQ_DIM_MAX];
     __shared__ float rn_sh[RB];
-    __shared__ float red_v[RB][4];
-    __shared__ int red_i[RB][4];
+    __shared__ float red_v[RB][RVQ_WAVES];
+    __shared__ int red_i[RB][RVQ_WAVES];
     __shared__ int best_sh[RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * RB;
-    for (int e = tid; e < RB * dim; e += 256) {
+    for (int e = tid; e < RB * dim; e += RVQ_THREADS) {
         const int rr = e / dim, d = e - rr * dim;
         r_sh[rr][d] = (row0 + rr < n_rows) ? z[(size_t)(row0 + rr) * dim + d] : 0.f;
         q_sh[rr][d] = 0.f;
@@ -43,41 +47,41 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     for (int st = 0; st < n_q; ++st) {
         const float* E = embed + (size_t)st * dim * size;
         const float* EN = enorm + (size_t)st * size;
-        if (tid < RB) {                                   // flatten.pow(2).sum(1)   (vq_module.py:94)
-            float s = 0.f;
-            for (int d = 0; d < dim; ++d) s = __fadd_rn(s, __fmul_rn(r_sh[tid][d], r_sh[tid][d]));
-            rn_sh[tid] = s;
+        if (wave < RB) {                                  // flatten.pow(2).sum(1)   (vq_module.py:94)
+            // one wave per row: squares summed by a fixed butterfly tree (the reference's own order is a
+            // vectorised tree inside torch.sum; the value only shifts all distances of a row together)
+            float v = (lane < dim) ? __fmul_rn(r_sh[wave][lane], r_sh[wave][lane]) : 0.f;
+            if (lane + 64 < dim) v = __fadd_rn(v, __fmul_rn(r_sh[wave][lane + 64], r_sh[wave][lane + 64]));
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+            if (lane == 0) rn_sh[wave] = v;
         }
         __syncthreads();
         float bv[RB]; int bi[RB];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) { bv[rr] = -INFINITY; bi[rr] = 0x7fffffff; }
-        for (int cb = 0; cb < size; cb += 1024) {
-            const int c0 = cb + 4 * tid;
-            if (c0 >= size) break;
-            float acc[RB][4];
+        for (int c = tid; c < size; c += RVQ_THREADS) {
+            float acc[RB];
 #pragma unroll
-            for (int rr = 0; rr < RB; ++rr) acc[rr][0] = acc[rr][1] = acc[rr][2] = acc[rr][3] = 0.f;
-            for (int d = 0; d < dim; ++d) {               // (2*flatten) @ embed   (vq_module.py:95)
-                const float4 e4 = *reinterpret_cast<const float4*>(E + (size_t)d * size + c0);
+            for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.f;
+            const float* Ec = E + c;
+            for (int d0 = 0; d0 < dim; d0 += 16) {        // (2*flatten) @ embed, d ascending   (vq_module.py:95)
+                float e[16];
 #pragma unroll
-                for (int rr = 0; rr < RB; ++rr) {
-                    const float x2 = 2.f * r_sh[rr][d];
-                    acc[rr][0] = fmaf(x2, e4.x, acc[rr][0]);
-                    acc[rr][1] = fmaf(x2, e4.y, acc[rr][1]);
-                    acc[rr][2] = fmaf(x2, e4.z, acc[rr][2]);
-                    acc[rr][3] = fmaf(x2, e4.w, acc[rr][3]);
-                }
+                for (int u = 0; u < 16; ++u) e[u] = (d0 + u < dim) ? Ec[(size_t)(d0 + u) * size] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (d0 + u < dim) {
+#pragma unroll
+                        for (int rr = 0; rr < RB; ++rr) acc[rr] = fmaf(2.f * r_sh[rr][d0 + u], e[u], acc[rr]);
+                    }
             }
-            const float4 en = *reinterpret_cast<const float4*>(EN + c0);
-            const float env[4] = {en.x, en.y, en.z, en.w};
+            const float en = EN[c];
 #pragma unroll
-            for (int rr = 0; rr < RB; ++rr)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {             // dist = (|r|^2 - 2rE) + |E|^2 ; argmax(-dist)
-                    const float dist = __fadd_rn(__fsub_rn(rn_sh[rr], acc[rr][c]), env[c]);
-                    argmax_merge(bv[rr], bi[rr], -dist, c0 + c);
-                }
+            for (int rr = 0; rr < RB; ++rr) {             // dist = (|r|^2 - 2rE) + |E|^2 ; argmax(-dist)
+                const float dist = __fadd_rn(__fsub_rn(rn_sh[rr], acc[rr]), en);
+                argmax_merge(bv[rr], bi[rr], -dist, c);
+            }
         }
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
@@ -93,12 +97,12 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         __syncthreads();
         if (tid < RB) {
             float v = red_v[tid][0]; int i = red_i[tid][0];
-            for (int w = 1; w < 4; ++w) argmax_merge(v, i, red_v[tid][w], red_i[tid][w]);
+            for (int w = 1; w < RVQ_WAVES; ++w) argmax_merge(v, i, red_v[tid][w], red_i[tid][w]);
             best_sh[tid] = i;
             if (row0 + tid < n_rows) idx[(size_t)st * n_rows + row0 + tid] = (long long)i + (long long)size * st;
         }
         __syncthreads();
-        for (int e = tid; e < RB * dim; e += 256) {       // straight-through + residual (vq_module.py:101-102,143-144)
+        for (int e = tid; e < RB * dim; e += RVQ_THREADS) {   // straight-through + residual (vq_module.py:101-102,143-144)
             const int rr = e / dim, d = e - rr * dim;
             const float r = r_sh[rr][d];
             const float q = E[(size_t)d * size + best_sh[rr]];
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         __syncthreads();
     }
     if (zq)
-        for (int e = tid; e < RB * dim; e += 256) {
+        for (int e = tid; e < RB * dim; e += RVQ_THREADS) {
             const int rr = e / dim, d = e - rr * dim;
             if (row0 + rr < n_rows) zq[(size_t)(row0 + rr) * dim + d] = q_sh[rr][d];
         }
@@ -155,14 +159,14 @@ using namespace adk;
 extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* enorm, int64_t* idx, float* zq,
                               int32_t n_rows, int32_t n_q, int32_t dim, int32_t size, void* stream) {
     if (!z || !embed || !enorm || !idx) return fail(ADK_ERR_ARG, "adk_rvq_encode: null pointer");
-    if (n_rows < 0 || n_q <= 0 || dim <= 0 || dim > RVQ_DIM_MAX || size <= 0 || size % 4)
-        return fail(ADK_ERR_SHAPE, "adk_rvq_encode: need 0 < dim <= 128, size % 4 == 0, n_q > 0");
+    if (n_rows < 0 || n_q <= 0 || dim <= 0 || dim > RVQ_DIM_MAX || size <= 0)
+        return fail(ADK_ERR_SHAPE, "adk_rvq_encode: need 0 < dim <= 128, size > 0, n_q > 0");
     if ((reinterpret_cast<uintptr_t>(embed) | reinterpret_cast<uintptr_t>(enorm)) & 15)
         return fail(ADK_ERR_ARG, "adk_rvq_encode: embed/enorm must be 16-byte aligned");
     if (n_rows == 0) return ADK_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int RB = 4;
-    hipLaunchKernelGGL(rvq_encode_kernel<RB>, dim3((n_rows + RB - 1) / RB), dim3(256), 0, s, z, embed, enorm,
+    hipLaunchKernelGGL(rvq_encode_kernel<RB>, dim3((n_rows + RB - 1) / RB), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
                        reinterpret_cast<long long*>(idx), zq, n_rows, n_q, dim, size);
     ADK_HIP_CHECK(hipGetLastError());
     return ADK_OK;

@@ -49,6 +49,7 @@ SYMBOLS = {
     "adk_last_error": (C.c_char_p, []),
     "adk_abi_version": (C.c_int, []),
     "adk_debug_flags": (C.c_int, [C.POINTER(_i32)]),
+    "adk_set_conv_cfg": (C.c_int, [_i32]),
     "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
     "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),
     "adk_rvq_encode": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

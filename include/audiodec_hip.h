@@ -44,6 +44,8 @@ int adk_abi_version(void);
 /* sticky device-side flags since the last call (bit 0: adk_rvq_lookup saw an out-of-range index,
  * where F.embedding would raise); reading synchronises the device and clears them */
 int adk_debug_flags(int32_t* out);
+/* tuning hook: force the MFMA conv tile config (0..5), -1 = heuristic (also env ADK_CONV_CFG) */
+int adk_set_conv_cfg(int32_t cfg);
 
 /* A view of one ring for one call. */
 typedef struct {
