@@ -22,12 +22,11 @@ struct ConvArgs {
     const float* in;   int in_rows, in_ch, in_row0, in_choff, in_gstride;   // in_row0 = (cursor - hist) mod R
     float* out;        int out_rows, out_ch, out_cursor, out_choff;
     const float* res;  int res_rows, res_ch, res_cursor, res_choff, res_gstride;
-    const float* w;    const float* bias;
+    const float* w;    const float* wfrag;  const float* bias;   // w: row-major [M][K]; wfrag: MFMA-fragment packed
     int cin_g, cout_g, groups, taps, stride, dilation, up, cout_real;
     int act_in, act_out; float slope;
     int batch, t_out, n_total;      // n_total = batch * t_out GEMM columns
     int ktot;                       // taps * cin_g
-    int dbg;                        // ablation bits (tuning only): 1 no global loads in loop, 2 no MFMA, 4 no lstore/barrier
 };
 
 __device__ __forceinline__ float act_apply(float x, int act, float slope) {
@@ -39,7 +38,9 @@ __device__ __forceinline__ float act_apply(float x, int act, float slope) {
 }
 
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
-int launch_conv_mfma(const ConvArgs& a, hipStream_t s);   // requires cin_g % 32 == 0 and 16-B alignment
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes);   // needs wfrag, cin_g % 32 == 0
+size_t conv_mfma_workspace_bytes();
+int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 bool conv_mfma_supported(const ConvArgs& a);
 int conv_mfma_pick(const ConvArgs& a);
 const char* conv_mfma_cfg_name(int pick);

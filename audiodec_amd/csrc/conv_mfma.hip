@@ -1,22 +1,35 @@
-// Implicit-GEMM causal conv on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact f32 FMA chain).
+// Implicit-GEMM causal conv on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chain),
+// persistent "stream-K" schedule.
 //
-//   D[m][n] = sum_k W[m][k] * X[k][n],   m = output channel (x phase for transposed convs),
-//   n = (stream b, output step t),       k = (tap j, input channel ci)
+//   D[m][n] = sum_k W[m][k] * act(X[k][n]),   m = output channel (x phase for transposed convs),
+//   n = (stream b, output step t),            k = (tap j, input channel ci)
 //
 // Replaces F.conv1d / F.conv_transpose1d as called from CausalConv1d.inference /
 // CausalConvTranspose1d.inference (layers/conv_layer.py:153-156, 194-197) and Conv1d1x1 (:28-32),
 // fused with the reference's surrounding element-wise ops (input ELU/LeakyReLU, bias, residual add).
 //
 // Many independent streams make N = B*T large even when one stream contributes a single step, so
-// every conv of the path with Cin % 32 == 0 is a GEMM with M in 32..1280, K in 32..2816.
-//   * 256 threads = 4 waves (64 lanes each), tile BM x BN, K-chunk = one tap x 32 channels
-//   * W chunk and gathered X chunk are staged in LDS (row stride 36 floats: conflict-free
-//     ds_write_b128 / ds_read_b128), double buffered, one barrier per chunk
-//   * X columns are gathered straight from the channel-last state rings: 128 contiguous bytes per
-//     (column, tap) -- coalesced along the channel axis; the causal history is just earlier rows
-//   * the input activation is applied once per staged element, before it lands in LDS
-//   * each lane reads 4 consecutive k per ds_read_b128 and feeds 4 MFMAs (the k order inside a
-//     chunk is permuted identically for both operands, which only reorders the exact f32 sum)
+// every conv of the path with Cin % 32 == 0 is a GEMM with M in 32..1280, K in 32..2816 -- but the
+// tile counts (60..2700) do not divide the 256 CUs, and the deep layers have few tiles with very
+// long K.  Hence:
+//   * grid = G persistent workgroups (G = 256 CUs x occupancy); the (tile, K-chunk) work units are
+//     split EVENLY over them in tile order (stream-K).  A workgroup that covers a whole tile writes
+//     it out directly; tiles cut by a range boundary leave raw partial accumulators in a workspace
+//     and a small fix-up kernel adds them in fixed (deterministic) order and runs the epilogue.
+//   * ranges are XCD-contiguous (block b -> range (b%8)*(G/8)+b/8) and tiles are ordered with the
+//     M-tile fastest, so the workgroups sharing one XCD's L2 walk neighbouring tiles: the weight
+//     panel of a group stays L2-resident, the activations stream from HBM once.
+//   * W is pre-packed in MFMA-fragment order (adk_pack_weights_mfma) and goes global -> VGPR
+//     directly, one coalesced 1 KiB wave-load per 32x8 fragment, prefetched a chunk ahead; it never
+//     touches LDS.
+//   * X columns are gathered from the channel-last state rings, 128 contiguous bytes per (column,
+//     tap): coalesced along the channel axis, the causal history is just earlier rows.  The input
+//     activation is applied once per staged element; the chunk lands in LDS (row stride 36 floats:
+//     conflict-free ds_write_b128 / ds_read_b128), double buffered, one barrier per 32-deep chunk,
+//     next chunk's global loads in flight under the MFMAs -- also across tile boundaries.
+//   * each lane reads 4 consecutive k per ds_read_b128 and feeds 4 MFMAs per accumulator (the k
+//     order inside a chunk is permuted identically for both operands: only the order of the exact
+//     f32 sum changes).
 #include "adk_common.h"
 #include <cstdlib>
 
@@ -24,133 +37,38 @@ namespace adk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int KC = 32;    // K chunk
-constexpr int LDK = 36;   // padded LDS row stride (floats)
+constexpr int KC = 64;    // K chunk: two 32-channel half-chunks (each one tap x 32 channels)
+constexpr int LDK = 68;   // padded LDS row stride (floats): conflict-free ds_write_b128 / ds_read_b128
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-    constexpr int WM = BM / WGM, WN = BN / WGN;       // wave tile
-    constexpr int MI = WM / 32, NJ = WN / 32;         // 32x32 MFMA tiles per wave
-    constexpr int RA = BM / 32, RB = BN / 32;         // staging rounds (32 rows per round)
-    static_assert(WGM * WGN == 4 && WM % 32 == 0 && WN % 32 == 0, "tile config");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [2][BM*LDK]
-    float* Bs = smem + 2 * BM * LDK;          // [2][BN*LDK]
+struct SkArgs {
+    float* ws;            // partial-tile workspace: [2*G][256 threads][NJ*16] floats
+    int G;                // persistent workgroups (multiple of 8)
+    int m_tiles, n_tiles, nchunks;
+    int cpt;              // 32-channel blocks per tap = cin_g / 32
+    int kgroups;          // 8-k fragments per 32-row m-tile, K zero-padded to a multiple of 64
+    int mt32_per_g;       // 32-row fragment tiles per group
+    unsigned in_bytes, w_bytes;   // buffer-descriptor extents of the input arena view / packed weights
+    float inv_t_out;
+    long long total;      // tiles * nchunks
+};
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int m_tiles = (a.cout_g + BM - 1) / BM;
-    const int g = blockIdx.y / m_tiles;
-    const int m0 = (blockIdx.y - g * m_tiles) * BM;
-    const int n0 = blockIdx.x * BN;
-    const int srow = tid >> 3, quad = tid & 7;        // staging: 8 lanes x float4 per 32-float row
+template <int ACT>
+__device__ __forceinline__ float act_in_apply(float x, float slope) {
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
+    return x;
+}
 
-    // per-thread column bookkeeping for the X gather (k-invariant)
-    const float* colp[RB];
-    int trow[RB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int n = n0 + srow + 32 * r;
-        if (n < a.n_total) {
-            const int b = n / a.t_out, t = n - b * a.t_out;
-            colp[r] = a.in + (size_t)b * a.in_rows * a.in_ch + a.in_choff + g * a.in_gstride + 4 * quad;
-            trow[r] = a.in_row0 + t * a.stride;
-        } else {
-            colp[r] = nullptr;
-            trow[r] = 0;
-        }
-    }
-    const float* wp[RA];
-#pragma unroll
-    for (int r = 0; r < RA; ++r) {
-        const int m = m0 + srow + 32 * r;
-        wp[r] = (m < a.cout_g) ? a.w + (size_t)(g * a.cout_g + m) * a.ktot + 4 * quad : nullptr;
-    }
+__device__ __forceinline__ long long sk_u0(int r, const SkArgs& sk) { return (long long)r * sk.total / sk.G; }
 
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    float4 ra[RA], rb[RB];
-    const int nchunks = a.ktot / KC;
-
-    auto gload = [&](int kc) {
-        const int k0 = kc * KC;
-        const int tap = k0 / a.cin_g;
-        const int ci0 = k0 - tap * a.cin_g;
-        const int roff = tap * a.dilation;
-#pragma unroll
-        for (int r = 0; r < RA; ++r)
-            ra[r] = wp[r] ? *reinterpret_cast<const float4*>(wp[r] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            int row = trow[r] + roff;
-            if (row >= a.in_rows) row -= a.in_rows;
-            rb[r] = colp[r] ? *reinterpret_cast<const float4*>(colp[r] + (size_t)row * a.in_ch + ci0)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* Ab = As + buf * BM * LDK;
-        float* Bb = Bs + buf * BN * LDK;
-#pragma unroll
-        for (int r = 0; r < RA; ++r)
-            *reinterpret_cast<float4*>(Ab + (srow + 32 * r) * LDK + 4 * quad) = ra[r];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            float4 v = rb[r];
-            if (a.act_in != ADK_ACT_NONE) {
-                v.x = act_apply(v.x, a.act_in, a.slope);
-                v.y = act_apply(v.y, a.act_in, a.slope);
-                v.z = act_apply(v.z, a.act_in, a.slope);
-                v.w = act_apply(v.w, a.act_in, a.slope);
-            }
-            *reinterpret_cast<float4*>(Bb + (srow + 32 * r) * LDK + 4 * quad) = v;
-        }
-    };
-
-    gload(0);
-    lstore(0);
-    __syncthreads();
-
+// Epilogue for one wave's 32 x (32*NJ) accumulator block: bias, residual, output activation, store.
+// Lane holds column n = n0w + 32*j + (lane&31) and rows ml0 + 8*qd + 4*(lane>>5) + {0..3}.
+template <int NJ>
+__device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&acc)[NJ], int g, int ml0, int n0w, int lane) {
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < nchunks && !(a.dbg & 1)) gload(kc + 1);          // global loads in flight under the MFMAs
-        const float* Ab = As + cur * BM * LDK + (wm * WM + l31) * LDK + 4 * lh;
-        const float* Bb = Bs + cur * BN * LDK + (wn * WN + l31) * LDK + 4 * lh;
-        if (!(a.dbg & 2))
-#pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
-            float4 av[MI], bv[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) av[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDK + q * 8);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + q * 8);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (!(a.dbg & 4)) {
-        if (kc + 1 < nchunks) lstore(cur ^ 1);
-        __syncthreads();
-        }
-    }
-
-    // epilogue: lane holds column n = ..+(lane&31), rows 8*qd + 4*(lane>>5) + {0..3} of each 32x32 tile
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
+        const int n = n0w + j * 32 + l31;
         if (n >= a.n_total) continue;
         const int b = n / a.t_out, t = n - b * a.t_out;
         const float* resp = nullptr;
@@ -162,100 +80,418 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         float* outb = a.out + (size_t)b * a.out_rows * a.out_ch + a.out_choff;
         const int obase = a.out_cursor + t * a.up;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int ml = m0 + wm * WM + i * 32 + 8 * qd + 4 * lh;     // row within the group
-                if (ml >= a.cout_g) continue;
-                const int mg = g * a.cout_g + ml;
-                float4 v = make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
-                if (a.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + mg);
-                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-                }
-                if (resp) {
-                    const float4 rr = *reinterpret_cast<const float4*>(resp + ml);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                }
-                if (a.act_out != ADK_ACT_NONE) {
-                    v.x = act_apply(v.x, a.act_out, 0.f); v.y = act_apply(v.y, a.act_out, 0.f);
-                    v.z = act_apply(v.z, a.act_out, 0.f); v.w = act_apply(v.w, a.act_out, 0.f);
-                }
-                int orow = obase, ocol = mg;
-                if (a.up > 1) { const int ph = mg / a.cout_real; orow += ph; ocol = mg - ph * a.cout_real; }
-                if (orow >= a.out_rows) orow -= a.out_rows;
-                *reinterpret_cast<float4*>(outb + (size_t)orow * a.out_ch + ocol) = v;
+        for (int qd = 0; qd < 4; ++qd) {
+            const int ml = ml0 + 8 * qd + 4 * lh;
+            if (ml >= a.cout_g) continue;
+            const int mg = g * a.cout_g + ml;
+            float4 v = make_float4(acc[j][4 * qd], acc[j][4 * qd + 1], acc[j][4 * qd + 2], acc[j][4 * qd + 3]);
+            if (a.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(a.bias + mg);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
+            if (resp) {
+                const float4 rr = *reinterpret_cast<const float4*>(resp + ml);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (a.act_out != ADK_ACT_NONE) {
+                v.x = act_apply(v.x, a.act_out, 0.f); v.y = act_apply(v.y, a.act_out, 0.f);
+                v.z = act_apply(v.z, a.act_out, 0.f); v.w = act_apply(v.w, a.act_out, 0.f);
+            }
+            int orow = obase, ocol = mg;
+            if (a.up > 1) { const int ph = mg / a.cout_real; orow += ph; ocol = mg - ph * a.cout_real; }
+            if (orow >= a.out_rows) orow -= a.out_rows;
+            *reinterpret_cast<float4*>(outb + (size_t)orow * a.out_ch + ocol) = v;
+        }
+    }
+}
+
+// tile id -> (group, m-tile, n-tile); M-tile fastest so neighbouring tiles share the X columns and
+// all tiles of a group share the (L2-resident) weight panel
+__device__ __forceinline__ void sk_tile_coords(int tile, const SkArgs& sk, int& g, int& mt, int& nt) {
+    mt = tile % sk.m_tiles;
+    const int rest = tile / sk.m_tiles;
+    nt = rest % sk.n_tiles;
+    g = rest / sk.n_tiles;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// n / d for 0 <= n < 2^24 via the f32 reciprocal (exact after one correction step)
+__device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
+    int q = (int)(__int2float_rn(n) * inv_d);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; }
+    return q;
+}
+
+// Main kernel.  One iteration = one 64-deep K chunk (two 32-channel half-chunks, which may belong to
+// different taps): 32*NJ MFMAs per wave (>= 4096 cycles) between barriers, so the global loads issued
+// at the top of an iteration (measured latency under MFMA load ~1.5 us) have landed when the bottom
+// of the iteration stores them to LDS.  With one or two waves per SIMD every instruction between two
+// MFMA bursts is exposed, so per-chunk addressing is reduced to buffer loads with one per-thread VGPR
+// offset per staged column (updated by adds) and scalar offsets for the weight stream; columns past
+// N and the zero-padded K tail read out of bounds (= 0) instead of branching.
+template <int WGM, int WGN, int NJ, int ACT>
+__global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) {
+    constexpr int BN = 32 * NJ * WGN;
+    constexpr int RB = BN / 16;                       // staging rounds: 16 columns x 16 quads per round
+    static_assert(WGM * WGN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float Bs[];   // [2][BN*LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int srow = tid >> 4, quad = tid & 15;       // staged column (mod 16) and 16-byte piece of the 64-float row
+    const int half = quad >> 3;                       // which 32-channel half-chunk this thread stages
+
+    // XCD-contiguous range of work units
+    const int r = (int)(blockIdx.x & 7) * (sk.G >> 3) + (int)(blockIdx.x >> 3);
+    const long long u0 = sk_u0(r, sk), u1 = sk_u0(r + 1, sk);
+    if (u0 >= u1) return;
+
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, sk.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, sk.w_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)a.in_ch * 4u;
+    const unsigned ring_bytes = (unsigned)a.in_rows * row_bytes;
+    const unsigned dil_bytes = (unsigned)a.dilation * row_bytes;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- staging state: describes the NEXT chunk to be loaded ----
+    int s_tile, s_kc;                                  // wave-uniform
+    int s_g = 0, s_mt = 0, s_nt = 0;
+    unsigned s_wbase = 0;                              // byte offset of this wave's fragment stream (OOB if none)
+    int t_tap, t_cblk;                                 // per thread: tap / 32-channel block of ITS half-chunk
+    unsigned colb[RB], rowb[RB];                       // per staged column: stream+channel base, ring row (tap applied)
+
+    auto stage_tile = [&](int tile, int kc0) {
+        sk_tile_coords(tile, sk, s_g, s_mt, s_nt);
+        s_tile = tile; s_kc = kc0;
+        const int j = 2 * kc0 + half;                  // index of this thread's 32-deep half-chunk
+        t_tap = j / sk.cpt; t_cblk = j - t_tap * sk.cpt;
+        const int n0 = s_nt * BN;
+        const unsigned tap_bytes = (unsigned)t_tap * dil_bytes;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int n = n0 + srow + 16 * rr;
+            const int nn = n < a.n_total ? n : 0;
+            const int b = fast_div(nn, a.t_out, sk.inv_t_out), t = nn - b * a.t_out;
+            int row = a.in_row0 + t * a.stride;
+            if (row >= a.in_rows) row -= a.in_rows;
+            unsigned rbv = (unsigned)row * row_bytes + tap_bytes;
+            if (rbv >= ring_bytes) rbv -= ring_bytes;
+            rowb[rr] = rbv;
+            colb[rr] = n < a.n_total ? ((unsigned)b * ring_bytes + (unsigned)(a.in_choff + s_g * a.in_gstride + 4 * (quad & 7)) * 4u) : OOB;
+        }
+        const int mtile32 = s_mt * WGM + wm;           // 32-row fragment tile inside the group
+        s_wbase = mtile32 < sk.mt32_per_g ? (unsigned)((s_g * sk.mt32_per_g + mtile32) * sk.kgroups) * 1024u : 0xfff00000u;
+    };
+    auto stage_advance = [&]() {                       // staged chunk -> next chunk (maybe next tile)
+        ++s_kc;
+        if (s_kc == sk.nchunks) { stage_tile(s_tile + 1, 0); return; }
+        t_cblk += 2;                                   // this thread's half-chunk moves on by two 32-blocks
+        while (t_cblk >= sk.cpt) {
+            t_cblk -= sk.cpt; ++t_tap;
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                unsigned rbv = rowb[rr] + dil_bytes;
+                if (rbv >= ring_bytes) rbv -= ring_bytes;
+                rowb[rr] = rbv;
+            }
+        }
+    };
+
+    float4 rb[RB];
+    float4 a_nxt[8];
+    auto gload = [&]() {
+        const bool k_ok = t_tap < a.taps;              // false on the zero-padded K tail
+        const unsigned cb = (unsigned)t_cblk * 128u;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const unsigned vo = (k_ok && colb[rr] != OOB) ? colb[rr] + rowb[rr] + cb : OOB;
+            rb[rr] = buf_load4(rsrc_in, vo, 0);
+        }
+        const unsigned sa = s_wbase + (unsigned)s_kc * 8192u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a_nxt[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
+    };
+    auto lstore = [&](int buf) {
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            float4 v = rb[rr];
+            v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
+            v.z = act_in_apply<ACT>(v.z, a.slope); v.w = act_in_apply<ACT>(v.w, a.slope);
+            *reinterpret_cast<float4*>(Bb + (srow + 16 * rr) * LDK + 4 * quad) = v;
+        }
+    };
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // ---- prologue: first chunk into LDS buffer 0 ----
+    int tile = (int)(u0 / sk.nchunks);
+    int kc = (int)(u0 - (long long)tile * sk.nchunks);
+    int seg_start_kc = kc;                             // first chunk of the current segment
+    bool first_seg = true;                             // the segment that starts at u0
+    stage_tile(tile, kc);
+    gload();
+    lstore(0);
+    float4 a_cur[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a_cur[q] = a_nxt[q];
+    int cur_g = s_g, cur_mt = s_mt, cur_nt = s_nt;
+    __syncthreads();
+
+    int cur = 0;
+    const int n_units = (int)(u1 - u0);
+    for (int it = 0; it < n_units; ++it) {
+        // -- issue the next chunk's global loads (possibly of the next tile) --
+        const bool has_next = (it + 1 < n_units);
+        if (has_next) {
+            stage_advance();
+            gload();
+        }
+        // -- MFMAs on the current chunk --
+        const float* Bb = Bs + cur * BN * LDK + (wn * NJ * 32 + l31) * LDK + 4 * lh;
+        {
+            float4 bv[2][NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q + 1 < 8) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) bv[(q + 1) & 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK + (q + 1) * 8);
+                }
+                const float4 av = a_cur[q];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[q & 1][j].x, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[q & 1][j].y, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[q & 1][j].z, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[q & 1][j].w, acc[j], 0, 0, 0);
+            }
+        }
+        // -- stage the next chunk --
+        if (has_next) lstore(cur ^ 1);
+        // -- end of this tile's segment? --
+        if (kc == sk.nchunks - 1 || !has_next) {
+            const int ml0 = (cur_mt * WGM + wm) * 32;
+            const int n0w = cur_nt * BN + wn * NJ * 32;
+            if (seg_start_kc == 0 && kc == sk.nchunks - 1) {
+                sk_epilogue<NJ>(a, acc, cur_g, ml0, n0w, lane);
+            } else {
+                // raw partial accumulators; slot 0 = the segment starting at u0, slot 1 = the other one
+                float* wsp = sk.ws + ((size_t)(2 * r + (first_seg ? 0 : 1)) * 256 + tid) * (NJ * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4)
+                        *reinterpret_cast<float4*>(wsp + j * 16 + 4 * e4) =
+                            make_float4(acc[j][4 * e4], acc[j][4 * e4 + 1], acc[j][4 * e4 + 2], acc[j][4 * e4 + 3]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+            seg_start_kc = 0;
+            first_seg = false;
+            cur_g = s_g; cur_mt = s_mt; cur_nt = s_nt;   // staged tile = the next tile (if any)
+        }
+        __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a_cur[q] = a_nxt[q];
+        if (++kc == sk.nchunks) kc = 0;
+    }
+}
+
+// One workgroup per range boundary: if the boundary cuts a tile and is the FIRST cut inside that tile,
+// add the partial accumulators of all contributing ranges in range order and run the epilogue.
+template <int WGM, int WGN, int NJ>
+__global__ __launch_bounds__(256) void conv_sk_fixup_kernel(ConvArgs a, SkArgs sk) {
+    constexpr int BN = 32 * NJ * WGN;
+    const int rbd = blockIdx.x + 1;                    // boundary between range rbd-1 and rbd
+    const long long ub = sk_u0(rbd, sk);
+    if (ub >= sk.total || ub % sk.nchunks == 0) return;           // boundary falls between tiles
+    const int tile = (int)(ub / sk.nchunks);
+    const long long t0 = (long long)tile * sk.nchunks, t1 = t0 + sk.nchunks;
+    if (sk_u0(rbd - 1, sk) > t0) return;               // an earlier boundary also cuts this tile: it owns the fix-up
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int rr = rbd - 1; rr < sk.G; ++rr) {
+        const long long s0 = sk_u0(rr, sk), s1 = sk_u0(rr + 1, sk);
+        if (s0 >= t1) break;
+        if (s1 <= s0) continue;
+        const long long lo = s0 > t0 ? s0 : t0;
+        const int slot = (lo == s0) ? 0 : 1;           // the segment that starts the range is slot 0
+        const float* wsp = sk.ws + ((size_t)(2 * rr + slot) * 256 + tid) * (NJ * 16);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const float4 v = *reinterpret_cast<const float4*>(wsp + j * 16 + 4 * e4);
+                acc[j][4 * e4] += v.x; acc[j][4 * e4 + 1] += v.y; acc[j][4 * e4 + 2] += v.z; acc[j][4 * e4 + 3] += v.w;
+            }
+    }
+    int g, mt, nt;
+    sk_tile_coords(tile, sk, g, mt, nt);
+    sk_epilogue<NJ>(a, acc, g, (mt * WGM + wm) * 32, nt * BN + wn * NJ * 32, lane);
+}
+
+// fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
+// lane (i = lane&31, h = lane>>5) holds W[32*mt + i][8*kg + 4*h + 0..3]; rows >= cout_g and the K
+// tail (K is padded to a multiple of 64) are zero.
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int groups, int cout_g, int ktot) {
+    const int mt32 = (cout_g + 31) / 32, kg = (ktot + 63) / 64 * 8;
+    const long long total = (long long)groups * mt32 * kg * 256;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        long long rest = i >> 8;
+        const int kgi = (int)(rest % kg); rest /= kg;
+        const int mt = (int)(rest % mt32); const int g = (int)(rest / mt32);
+        const int row = 32 * mt + (lane & 31);
+        const int k = 8 * kgi + 4 * (lane >> 5) + e;
+        out[i] = (row < cout_g && k < ktot) ? w[((size_t)g * cout_g + row) * ktot + k] : 0.f;
     }
 }
 
 bool conv_mfma_supported(const ConvArgs& a) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (a.cin_g % KC != 0 || a.cout_g % 4 != 0 || a.cout_real % 4 != 0) return false;
+    if (!a.wfrag) return false;
+    // 32-bit buffer addressing: input arena view < 2 GiB, packed weights < 4 GiB, N < 2^24
+    if ((unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull >= 0x80000000ull) return false;
+    if ((unsigned long long)a.groups * ((a.cout_g + 31) / 32) * ((a.ktot + 63) / 64 * 8) * 1024ull >= 0xfff00000ull) return false;
+    if (a.n_total >= (1 << 24)) return false;
+    if (a.cin_g % 32 != 0 || a.cout_g % 4 != 0 || a.cout_real % 4 != 0) return false;
     if (a.in_ch % 4 || a.in_choff % 4 || a.in_gstride % 4 || a.out_ch % 4 || a.out_choff % 4) return false;
-    if (!al16(a.in) || !al16(a.out) || !al16(a.w) || (a.bias && !al16(a.bias))) return false;
+    if (!al16(a.in) || !al16(a.out) || !al16(a.wfrag) || (a.bias && !al16(a.bias))) return false;
     if (a.res && (a.res_ch % 4 || a.res_choff % 4 || a.res_gstride % 4 || !al16(a.res))) return false;
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
 namespace {
-struct Cfg { int bm, bn; };
-template <int BM, int BN, int WGM, int WGN>
-int launch_cfg(const ConvArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    constexpr size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
-    auto kern = conv_mfma_kernel<BM, BN, WGM, WGN>;
-    if (!attr_set) {
-        ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+struct Cfg { int wgm, wgn, nj; const char* name; };
+const Cfg kCfgs[6] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"}, {2, 2, 1, "conv_sk<64x64>"},
+                      {2, 2, 2, "conv_sk<64x128>"}, {1, 4, 1, "conv_sk<32x128>"}, {1, 4, 2, "conv_sk<32x256>"}};
+int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
+int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
+
+template <int WGM, int WGN, int NJ>
+int launch_cfg(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes) {
+    constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN;
+    constexpr size_t lds = 2ull * BN * LDK * sizeof(float);
+    SkArgs sk;
+    sk.m_tiles = (a.cout_g + BM - 1) / BM;
+    sk.n_tiles = (a.n_total + BN - 1) / BN;
+    sk.nchunks = (a.ktot + KC - 1) / KC;
+    sk.cpt = a.cin_g / 32;
+    sk.kgroups = sk.nchunks * (KC / 8);
+    sk.mt32_per_g = (a.cout_g + 31) / 32;
+    sk.inv_t_out = 1.0f / (float)a.t_out;
+    {
+        const unsigned long long inb = (unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull;
+        const unsigned long long wb = (unsigned long long)a.groups * sk.mt32_per_g * sk.kgroups * 1024ull;
+        if (inb >= 0x80000000ull || wb >= 0xfff00000ull || a.n_total >= (1 << 24))
+            return fail(ADK_ERR_SHAPE, "conv: problem too large for the 32-bit buffer addressing of the MFMA kernel");
+        sk.in_bytes = (unsigned)inb; sk.w_bytes = (unsigned)wb;
     }
-    const int m_tiles = (a.cout_g + BM - 1) / BM;
-    dim3 grid((a.n_total + BN - 1) / BN, m_tiles * a.groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    const long long tiles = (long long)sk.m_tiles * sk.n_tiles * a.groups;
+    sk.total = tiles * sk.nchunks;
+    long long G = 256LL * g_occ;
+    if (G > sk.total) G = (sk.total + 7) / 8 * 8;     // tiny problems: at most one unit per workgroup
+    sk.G = (int)G;
+    sk.ws = ws;
+    const size_t need = (size_t)2 * sk.G * 256 * NJ * 16 * sizeof(float);
+    if (!ws || need > ws_bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
+    if (a.act_in == ADK_ACT_ELU)
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU>), dim3(sk.G), dim3(256), lds, s, a, sk);
+    else if (a.act_in == ADK_ACT_LEAKY)
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY>), dim3(sk.G), dim3(256), lds, s, a, sk);
+    else if (a.act_in == ADK_ACT_NONE)
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE>), dim3(sk.G), dim3(256), lds, s, a, sk);
+    else
+        return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
     ADK_HIP_CHECK(hipGetLastError());
+    bool cut = false;                                  // does any range boundary fall inside a tile?
+    if (sk.nchunks == 1) cut = false;                  // one unit per tile: nothing to cut
+    else if (sk.total % sk.G == 0) cut = ((sk.total / sk.G) % sk.nchunks) != 0;
+    else cut = true;
+    if (cut && sk.G > 1) {
+        hipLaunchKernelGGL((conv_sk_fixup_kernel<WGM, WGN, NJ>), dim3(sk.G - 1), dim3(256), 0, s, a, sk);
+        ADK_HIP_CHECK(hipGetLastError());
+    }
     return ADK_OK;
 }
 }  // namespace
 
-// Tile choice: the largest tile that still yields >= 2 workgroups per CU (256 CUs); M padding
-// waste is avoided by matching BM to cout_g.  ADK_CONV_CFG=<0..5> forces a config (tuning aid).
-static const Cfg kCfgs[6] = {{128, 128}, {64, 128}, {32, 256}, {64, 64}, {128, 32}, {32, 128}};
-
-static int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
-
 void conv_mfma_force_cfg(int cfg) { g_forced_cfg = cfg; }
+
+size_t conv_mfma_workspace_bytes() {
+    if (g_occ < 0) { const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2; }
+    return (size_t)2 * 256 * g_occ * 256 * 4 * 16 * sizeof(float);       // NJ <= 4
+}
 
 int conv_mfma_pick(const ConvArgs& a) {
     if (g_forced_cfg == -2) { const char* e = getenv("ADK_CONV_CFG"); g_forced_cfg = e ? atoi(e) : -1; }
-    const int forced = g_forced_cfg;
-    if (forced >= 0 && forced <= 5) return forced;
-    // Measured on MI355X (profiles/r1_cfg_sweep.md): with one barrier per 32-deep K chunk the 32x32
-    // wave tile (one accumulator per wave, >= 3 workgroups per CU) beats the larger tiles on every
-    // layer of the path, so pick among the three 4-wave arrangements of it by the M extent.
-    if (a.cout_g % 128 == 0) return 4;      // 128 x 32
-    if (a.cout_g % 64 == 0) return 3;       // 64 x 64
-    return 5;                               // 32 x 128
+    if (g_forced_cfg >= 0 && g_forced_cfg <= 5) return g_forced_cfg;
+    // Measured over every layer of the path at 256 streams (profiles/r1_streamk_cfg_sweep.md): the
+    // 32x32 wave tile wins everywhere -- 64x64 workgroup tiles when the group has >= 64 output
+    // channels, 32x128 otherwise.  (The wider tiles are kept for tuning via ADK_CONV_CFG.)
+    return (a.cout_g % 64 == 0) ? 2 : 4;
 }
 
-const char* conv_mfma_cfg_name(int pick) {
-    static const char* names[6] = {"conv_mfma<128,128>", "conv_mfma<64,128>", "conv_mfma<32,256>",
-                                   "conv_mfma<64,64>", "conv_mfma<128,32>", "conv_mfma<32,128>"};
-    return names[pick];
-}
+const char* conv_mfma_cfg_name(int pick) { return kCfgs[pick].name; }
 
-int launch_conv_mfma(const ConvArgs& a0, hipStream_t s) {
-    if (a0.n_total == 0) return ADK_OK;
-    ConvArgs a = a0;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ADK_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes) {
+    if (a.n_total == 0) return ADK_OK;
+    (void)conv_mfma_workspace_bytes();
     switch (conv_mfma_pick(a)) {
-        case 0: return launch_cfg<128, 128, 2, 2>(a, s);
-        case 1: return launch_cfg<64, 128, 2, 2>(a, s);
-        case 2: return launch_cfg<32, 256, 1, 4>(a, s);
-        case 3: return launch_cfg<64, 64, 2, 2>(a, s);
-        case 4: return launch_cfg<128, 32, 4, 1>(a, s);
-        default: return launch_cfg<32, 128, 1, 4>(a, s);
+        case 0: return launch_cfg<4, 1, 2>(a, s, ws, ws_bytes);
+        case 1: return launch_cfg<4, 1, 4>(a, s, ws, ws_bytes);
+        case 2: return launch_cfg<2, 2, 1>(a, s, ws, ws_bytes);
+        case 3: return launch_cfg<2, 2, 2>(a, s, ws, ws_bytes);
+        case 4: return launch_cfg<1, 4, 1>(a, s, ws, ws_bytes);
+        default: return launch_cfg<1, 4, 2>(a, s, ws, ws_bytes);
     }
+}
+
+int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s) {
+    const long long total = (long long)groups * ((cout_g + 31) / 32) * ((ktot + 63) / 64 * 8) * 256;
+    if (total == 0) return ADK_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, out, groups, cout_g, ktot);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
 }
 
 }  // namespace adk

@@ -15,7 +15,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 static int build_args(const adk_conv_desc& d, const adk_ring_view& in, const adk_ring_view& out,
                       const adk_ring_view& res, int batch, int t_out, ConvArgs& a) {
-    if (!d.w || !in.base || !out.base) return fail(ADK_ERR_ARG, "conv: null weight/in/out pointer");
+    if ((!d.w && !d.w_frag) || !in.base || !out.base) return fail(ADK_ERR_ARG, "conv: null weight/in/out pointer");
     if (d.cin_g <= 0 || d.cout_g <= 0 || d.groups <= 0 || d.taps <= 0 || d.stride <= 0 || d.dilation <= 0 ||
         d.up <= 0 || d.cout_real <= 0 || d.hist < 0)
         return fail(ADK_ERR_SHAPE, "conv: non-positive geometry");
@@ -48,24 +48,38 @@ static int build_args(const adk_conv_desc& d, const adk_ring_view& in, const adk
     a.out = out.base; a.out_rows = out.rows; a.out_ch = out.channels; a.out_cursor = out.cursor; a.out_choff = out.ch_off;
     a.res = res.base; a.res_rows = res.rows; a.res_ch = res.channels; a.res_cursor = res.cursor; a.res_choff = res.ch_off;
     a.res_gstride = d.res_group_stride;
-    a.w = d.w; a.bias = d.bias;
+    a.w = d.w; a.wfrag = d.w_frag; a.bias = d.bias;
     a.cin_g = d.cin_g; a.cout_g = d.cout_g; a.groups = d.groups; a.taps = d.taps; a.stride = d.stride;
     a.dilation = d.dilation; a.up = d.up; a.cout_real = d.cout_real;
     a.act_in = d.act_in; a.act_out = d.act_out; a.slope = d.act_in_slope;
-    a.dbg = 0;
     a.batch = batch; a.t_out = t_out; a.n_total = batch * t_out; a.ktot = d.taps * d.cin_g;
     return ADK_OK;
 }
 
-static int run_conv(const ConvArgs& a, int impl, hipStream_t s) {
-    if (impl == ADK_IMPL_DIRECT) return launch_conv_direct(a, s);
+struct Workspace { float* ptr = nullptr; size_t bytes = 0; };
+
+static int ensure_workspace(Workspace& w) {
+    const size_t need = conv_mfma_workspace_bytes();
+    if (w.ptr && w.bytes >= need) return ADK_OK;
+    if (w.ptr) (void)hipFree(w.ptr);
+    w.ptr = nullptr; w.bytes = 0;
+    ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w.ptr), need));
+    w.bytes = need;
+    return ADK_OK;
+}
+
+static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
     const bool ok = conv_mfma_supported(a);
-    if (impl == ADK_IMPL_MFMA) {
-        if (!ok) return fail(ADK_ERR_SHAPE, "conv: MFMA kernel needs cin_g % 32 == 0 and 16-byte aligned rows");
-        return launch_conv_mfma(a, s);
+    const bool want_mfma = (impl == ADK_IMPL_MFMA) || (impl == ADK_IMPL_AUTO && ok && a.groups * a.cout_g >= 32);
+    if (impl == ADK_IMPL_MFMA && !ok)
+        return fail(ADK_ERR_SHAPE, "conv: MFMA kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
+    if (want_mfma) {
+        int rc = ensure_workspace(ws);
+        if (rc != ADK_OK) return rc;
+        return launch_conv_mfma(a, s, ws.ptr, ws.bytes);
     }
-    // AUTO: matrix cores whenever the shape is GEMM-like; tiny M (Cout == 1) stays on the VALU kernel
-    if (ok && a.groups * a.cout_g >= 32) return launch_conv_mfma(a, s);
+    // VALU kernel: Cin = 1 / Cout = 1 layers and anything the matrix-core kernel does not take
+    if (!a.w) return fail(ADK_ERR_ARG, "conv: the VALU kernel needs row-major weights (w)");
     return launch_conv_direct(a, s);
 }
 
@@ -83,7 +97,19 @@ extern "C" int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_rin
     ConvArgs a;
     int rc = build_args(*d, in, out, res, batch, t_out, a);
     if (rc != ADK_OK) return rc;
-    return run_conv(a, impl, static_cast<hipStream_t>(stream));
+    static thread_local Workspace tls_ws;             // op-level calls: one scratch per host thread
+    return run_conv(a, impl, static_cast<hipStream_t>(stream), tls_ws);
+}
+
+extern "C" int64_t adk_packed_weight_floats(int32_t groups, int32_t cout_g, int32_t ktot) {
+    if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 8) return -1;
+    return (int64_t)groups * ((cout_g + 31) / 32) * ((ktot + 63) / 64 * 8) * 256;
+}
+
+extern "C" int adk_pack_weights_mfma(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream) {
+    if (!w || !out) return fail(ADK_ERR_ARG, "adk_pack_weights_mfma: null pointer");
+    if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 8) return fail(ADK_ERR_SHAPE, "adk_pack_weights_mfma: need ktot % 8 == 0");
+    return launch_pack_weights(w, out, groups, cout_g, ktot, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -95,6 +121,7 @@ struct adk_program {
     int batch = 0, max_frames = 0, n_ext = 0;
     const float* weights = nullptr; int64_t weights_floats = 0;
     float* arena = nullptr; int64_t arena_floats = 0;
+    Workspace ws;
     bool profiling = false;
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
     std::vector<float> last_ms;
@@ -136,7 +163,12 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             if (!ring_ok(o.in_ring) || !ring_ok(o.out_ring) || (o.res_ring >= 0 && !ring_ok(o.res_ring)))
                 return bail(ADK_ERR_ARG, "program_create: op references an unknown ring");
             const long long wn = (long long)o.conv.groups * o.conv.cout_g * o.conv.taps * o.conv.cin_g;
-            if (o.w_off < 0 || o.w_off % 4 || o.w_off + wn > weights_floats) return bail(ADK_ERR_SHAPE, "program_create: weight offset out of range");
+            if (o.w_off < 0 && o.wf_off < 0) return bail(ADK_ERR_ARG, "program_create: op has no weights");
+            if (o.w_off >= 0 && (o.w_off % 4 || o.w_off + wn > weights_floats)) return bail(ADK_ERR_SHAPE, "program_create: weight offset out of range");
+            if (o.wf_off >= 0) {
+                const long long wfn = adk_packed_weight_floats(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g);
+                if (wfn < 0 || o.wf_off % 4 || o.wf_off + wfn > weights_floats) return bail(ADK_ERR_SHAPE, "program_create: packed weight offset out of range");
+            }
             if (o.b_off >= 0 && (o.b_off % 4 || o.b_off + (long long)o.conv.groups * o.conv.cout_g > weights_floats))
                 return bail(ADK_ERR_SHAPE, "program_create: bias offset out of range");
             if (o.rate_out <= 0) return bail(ADK_ERR_SHAPE, "program_create: rate_out must be positive");
@@ -149,12 +181,17 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             return bail(ADK_ERR_ARG, "program_create: unknown op kind");
         }
     }
+    {
+        int rc = ensure_workspace(p->ws);
+        if (rc != ADK_OK) { delete p; return rc; }
+    }
     *out = p;
     return ADK_OK;
 }
 
 extern "C" void adk_program_destroy(adk_program* p) {
     if (!p) return;
+    if (p->ws.ptr) (void)hipFree(p->ws.ptr);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
 }
@@ -190,7 +227,8 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
         const adk_op_desc& o = p->ops[i];
         if (o.kind == ADK_OP_CONV) {
             adk_conv_desc d = o.conv;
-            d.w = p->weights + o.w_off;
+            d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
+            d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;
             d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
             adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
             adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
@@ -198,7 +236,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
             if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
             ConvArgs a;
             int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
-            if (rc == ADK_OK) rc = run_conv(a, o.impl, s);
+            if (rc == ADK_OK) rc = run_conv(a, o.impl, s, p->ws);
             if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
         } else {
             adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
@@ -222,7 +260,8 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
     std::string name = "ring_write";
     if (o.kind == ADK_OP_CONV) {
         adk_conv_desc d = o.conv;
-        d.w = p->weights + o.w_off;
+        d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
+        d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;
         d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
         alignas(16) static float aligned_dummy[4];   // stand-in for the (16-byte aligned) external buffers:
         void* ext[8];                                // only geometry/alignment is inspected, nothing is launched

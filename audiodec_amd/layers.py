@@ -18,7 +18,7 @@ import torch
 
 from . import native
 from .native import ConvDesc, RingView
-from .program import pack_conv, pack_convtr
+from .program import pack_conv, pack_convtr, pack_mfma, mfma_eligible
 
 _ACTS = {None: native.ACT_NONE, "ELU": native.ACT_ELU, "LeakyReLU": native.ACT_LEAKY, "Tanh": native.ACT_TANH}
 
@@ -70,6 +70,7 @@ class _CausalBase:
         out = torch.empty(self.batch, out_rows, out_ch, device=self.dev)
         d.act_in, d.act_in_slope, d.act_out = self.act_in, self.slope, self.act_out
         d.w = self.w_packed.data_ptr()
+        d.w_frag = self.w_frag.data_ptr() if self.w_frag is not None else None
         d.bias = self.b_packed.data_ptr() if self.b_packed is not None else None
         native.check(native.lib().adk_causal_conv(
             C.byref(d), _view(self.ring, self.rows, self.in_channels, self.cursor), _view(out, out_rows, out_ch, 0),
@@ -93,7 +94,10 @@ class CausalConv1d(_CausalBase):
     def load(self, weight, bias=None):
         assert tuple(weight.shape) == (self.out_channels, self.in_channels // self.groups, self.kernel_size)
         self.weight, self.bias = weight.detach().float().cpu(), (bias.detach().float().cpu() if bias is not None else None)
-        self.w_packed = pack_conv(self.weight).to(self.dev)
+        rows = pack_conv(self.weight)
+        self.w_packed = rows.to(self.dev)
+        ok = mfma_eligible(self.in_channels // self.groups, self.out_channels // self.groups, self.groups)
+        self.w_frag = pack_mfma(rows, self.groups).to(self.dev) if ok else None
         self.b_packed = self.bias.to(self.dev) if self.bias is not None else None
         return self
 
@@ -126,7 +130,10 @@ class CausalConvTranspose1d(_CausalBase):
     def load(self, weight, bias=None):
         assert tuple(weight.shape) == (self.in_channels, self.out_channels, self.kernel_size)
         self.weight, self.bias = weight.detach().float().cpu(), (bias.detach().float().cpu() if bias is not None else None)
-        self.w_packed = pack_convtr(self.weight, self.stride).to(self.dev)
+        rows = pack_convtr(self.weight, self.stride)
+        self.w_packed = rows.to(self.dev)
+        ok = mfma_eligible(self.in_channels, self.stride * self.out_channels, 1)
+        self.w_frag = pack_mfma(rows, 1).to(self.dev) if ok else None
         self.b_packed = self.bias.repeat(self.stride).to(self.dev) if self.bias is not None else None
         return self
 

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaudiodec_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
                 ("hist", C.c_int32), ("up", C.c_int32), ("cout_real", C.c_int32),
                 ("in_group_stride", C.c_int32), ("res_group_stride", C.c_int32),
                 ("act_in", C.c_int32), ("act_in_slope", C.c_float), ("act_out", C.c_int32),
-                ("w", C.c_void_p), ("bias", C.c_void_p)]
+                ("w", C.c_void_p), ("w_frag", C.c_void_p), ("bias", C.c_void_p)]
 
 
 class RingDesc(C.Structure):
@@ -39,7 +39,7 @@ class RingDesc(C.Structure):
 class OpDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_ring", C.c_int32), ("out_ring", C.c_int32), ("res_ring", C.c_int32),
                 ("in_ch_off", C.c_int32), ("out_ch_off", C.c_int32), ("res_ch_off", C.c_int32),
-                ("rate_out", C.c_int32), ("conv", ConvDesc), ("w_off", C.c_int64), ("b_off", C.c_int64),
+                ("rate_out", C.c_int32), ("conv", ConvDesc), ("w_off", C.c_int64), ("wf_off", C.c_int64), ("b_off", C.c_int64),
                 ("mean_off", C.c_int64), ("scale_off", C.c_int64), ("ext_src", C.c_int32), ("impl", C.c_int32)]
 
 
@@ -51,6 +51,8 @@ SYMBOLS = {
     "adk_debug_flags": (C.c_int, [C.POINTER(_i32)]),
     "adk_set_conv_cfg": (C.c_int, [_i32]),
     "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
+    "adk_packed_weight_floats": (C.c_int64, [_i32, _i32, _i32]),
+    "adk_pack_weights_mfma": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),
     "adk_rvq_encode": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "adk_rvq_lookup": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -53,6 +53,30 @@ def pack_convtr(w, stride):
     return torch.cat([old, new], dim=2).reshape(stride * co, 2 * ci).contiguous()
 
 
+def pack_mfma(w_rows, groups):
+    """Row-major GEMM rows [groups*cout_g][ktot] -> MFMA-fragment order (same layout as
+    adk_pack_weights_mfma): [g][m-tile of 32][k-group of 8][lane 64][4], lane (i = lane & 31,
+    h = lane >> 5) holding W[32*mt + i][8*kg + 4*h + 0..3]; rows beyond cout_g and the K tail
+    (K padded to a multiple of 64) are zero."""
+    m, ktot = w_rows.shape
+    cout_g = m // groups
+    assert ktot % 8 == 0
+    mt32 = (cout_g + 31) // 32
+    w = w_rows.reshape(groups, cout_g, ktot)
+    if mt32 * 32 != cout_g:
+        w = torch.cat([w, torch.zeros(groups, mt32 * 32 - cout_g, ktot)], 1)
+    kpad = (ktot + 63) // 64 * 64                      # the kernel walks K in 64-deep chunks
+    if kpad != ktot:
+        w = torch.cat([w, torch.zeros(groups, mt32 * 32, kpad - ktot)], 2)
+        ktot = kpad
+    w = w.reshape(groups, mt32, 32, ktot // 8, 2, 4)        # (g, mt, i, kg, h, e)
+    return w.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # (g, mt, kg, h, i, e): lane = h*32 + i
+
+
+def mfma_eligible(cin_g, cout_g, groups):
+    return cin_g % 32 == 0 and cout_g % 4 == 0 and groups * cout_g >= 32
+
+
 class Blob:
     """Packed fp32 weights; every tensor starts on a 16-byte boundary."""
 
@@ -107,7 +131,7 @@ class Builder:
         op.ext_src = ext_src
         op.mean_off = self.blob.add(mean) if mean is not None else -1
         op.scale_off = self.blob.add(scale) if scale is not None else -1
-        op.w_off, op.b_off = 0, -1
+        op.w_off, op.wf_off, op.b_off = -1, -1, -1
         op.rate_out = self.rings[out_ring]["rate"]
         self.ops.append(op)
         self.op_names.append("ring_write")
@@ -145,7 +169,10 @@ class Builder:
         op.in_ch_off = op.out_ch_off = op.res_ch_off = 0
         op.rate_out = rate_out
         op.conv = d
-        op.w_off = self.blob.add(packed)
+        if mfma_eligible(d.cin_g, d.cout_g, d.groups) and impl != native.IMPL_DIRECT:
+            op.w_off, op.wf_off = -1, self.blob.add(pack_mfma(packed, d.groups))
+        else:
+            op.w_off, op.wf_off = self.blob.add(packed), -1
         op.b_off = self.blob.add(bias) if bias is not None else -1
         op.mean_off = op.scale_off = -1
         op.ext_src = -1

@@ -6,6 +6,9 @@
  * INTEGRATION.md); every entry point names the reference method(s) it replaces.
  *
  * Conventions
+ *   - the matrix-core conv kernel keeps split-tile partial sums in a scratch workspace: a program owns
+ *     one (allocated in adk_program_create); op-level adk_causal_conv uses a per-host-thread one that
+ *     is allocated on that thread's first call
  *   - all data pointers are DEVICE pointers (fp32 unless stated); `stream` is a hipStream_t passed
  *     as void*; calls enqueue work on that stream and return without synchronising
  *   - return value: 0 = ADK_OK, negative = error (text via adk_last_error(), thread-local)
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 1
+#define ADK_ABI_VERSION 2
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -80,9 +83,20 @@ typedef struct {
     int32_t res_group_stride;
     int32_t act_in;  float act_in_slope;
     int32_t act_out;
-    const float* w;                      /* [groups*cout_g][taps*cin_g], tap-major / channel-minor   */
+    const float* w;                      /* [groups*cout_g][taps*cin_g], tap-major / channel-minor; may be NULL when
+                                            w_frag is given and the MFMA kernel is taken             */
+    const float* w_frag;                 /* the same weights in MFMA-fragment order (adk_pack_weights_mfma) or NULL:
+                                            without it only the VALU kernel can run                  */
     const float* bias;                   /* [groups*cout_g] or NULL                                  */
 } adk_conv_desc;
+
+/* Re-pack row-major conv weights [groups*cout_g][ktot] for the matrix-core kernel:
+ * out[g][m-tile of 32][k-group of 8][lane 0..63][4] with lane (i = lane&31, h = lane>>5) holding
+ * W[32*mt + i][8*kg + 4*h + 0..3]; rows beyond cout_g and the K tail (K is padded to a multiple
+ * of 64) are zero.  out needs
+ * adk_packed_weight_floats(groups, cout_g, ktot) floats; ktot % 8 == 0.  Done once at load time. */
+int64_t adk_packed_weight_floats(int32_t groups, int32_t cout_g, int32_t ktot);
+int adk_pack_weights_mfma(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream);
 
 int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
                     int32_t batch, int32_t t_out, int32_t impl, void* stream);
@@ -142,8 +156,9 @@ typedef struct {
     int32_t in_ring, out_ring, res_ring; /* ring ids; res_ring = -1: none                             */
     int32_t in_ch_off, out_ch_off, res_ch_off;
     int32_t rate_out;                    /* output steps per frame (t_out = frames * rate_out)        */
-    adk_conv_desc conv;                  /* conv.w / conv.bias ignored; use w_off / b_off             */
-    int64_t w_off, b_off;                /* float offsets into the weight blob; b_off < 0: no bias    */
+    adk_conv_desc conv;                  /* conv.w / w_frag / bias ignored; use the offsets below     */
+    int64_t w_off, wf_off, b_off;        /* float offsets into the weight blob (row-major weights, fragment-packed
+                                            weights, bias); < 0: absent (at least one of w_off / wf_off)     */
     int64_t mean_off, scale_off;         /* ADK_OP_RING_WRITE: offsets of mean/scale, < 0: none       */
     int32_t ext_src;                     /* ADK_OP_RING_WRITE: index into ext[] of the source rows    */
     int32_t impl;                        /* ADK_IMPL_*                                                */

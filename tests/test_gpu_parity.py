@@ -215,8 +215,10 @@ def test_rvq_indices_bit_exact_on_reference_latents(gpu, golden_dir):
 
 
 def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
-    """Streaming invariants on the HIP path: chunking is bit-exact, reset_buffer +
-    warm-up reproduces the initial state."""
+    """Streaming invariants on the HIP path.  Chunking must not change the codes
+    and may change the waveform only by fp32 round-off (the stream-K schedule splits the K sum of a
+    tile at points that depend on the number of columns in the call); the same call sequence is
+    bit-reproducible, and reset_buffer + warm-up reproduces the initial state exactly."""
     seed, B, hop = 99, 3, 300
     audio = np.stack([synth.synth_audio(seed, s, 8 * hop) for s in range(B)])
     ad = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 3)
@@ -224,13 +226,13 @@ def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
     ad2 = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 3)
     many = run_hip(ad2, audio, [hop, 2 * hop, hop, 3 * hop, hop])
     assert np.array_equal(one[1], many[1])
-    assert np.array_equal(one[0], many[0]) and np.array_equal(one[3], many[3])
-    # reset + re-warm == fresh
+    assert np.abs(one[0] - many[0]).max() < 1e-5 and np.abs(one[3] - many[3]).max() < 1e-5
+    # reset + re-warm == fresh, bit for bit (same call sequence -> same summation order)
     ad2.tx_encoder.reset_buffer(); ad2.rx_encoder.reset_buffer(); ad2.decoder.reset_buffer()
     ad2.tx_encoder.initial_encoder(8192, DEV)
     ad2.decoder.initial_decoder(ad2.rx_encoder.initial_encoder(8192, DEV))
     again = run_hip(ad2, audio, [8 * hop])
-    assert np.array_equal(one[1], again[1]) and np.array_equal(one[3], again[3])
+    assert np.array_equal(one[1], again[1]) and np.array_equal(one[0], again[0]) and np.array_equal(one[3], again[3])
 
 
 def test_error_behaviour(gpu, ckpt_root):

@@ -13,6 +13,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from audiodec_amd import native  # noqa: E402
 from audiodec_amd.native import ConvDesc, RingView  # noqa: E402
+from audiodec_amd.program import pack_mfma  # noqa: E402
 
 SHAPES = {  # cin_g, cout_g, groups, taps, stride, dil, t_out, up, act
     "s0": (256, 256, 3, 11, 1, 5, 5, 1, 2), "s1": (128, 128, 3, 11, 1, 5, 25, 1, 2),
@@ -47,7 +48,8 @@ def run(shape, cfg, B, iters, impl=native.IMPL_MFMA):
     d.cin_g, d.cout_g, d.groups, d.taps, d.stride, d.dilation, d.hist = cin_g, cout_g, groups, taps, stride, dil, hist
     d.up, d.cout_real, d.in_group_stride, d.res_group_stride = up, cout_real, cin_g, cout_g
     d.act_in, d.act_in_slope, d.act_out = act, 0.1, 0
-    d.w, d.bias = w.data_ptr(), bias.data_ptr()
+    wf = pack_mfma(w.cpu(), groups).to(dev)
+    d.w, d.w_frag, d.bias = w.data_ptr(), wf.data_ptr(), bias.data_ptr()
     lib.adk_set_conv_cfg(cfg)
     st = native.current_stream(dev)
     vin, vout, vres = view(ring, rows, cin_t, hist), view(out, t_out * up, cout_real, 0), view(None, 0, 0, 0)
