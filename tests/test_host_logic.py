@@ -1,0 +1,132 @@
+"""CPU: host-side logic -- model table, layer specs, synthetic checkpoints, lowering to programs,
+weight packing, loader strictness."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiodec_amd import arch, configs, program, synth
+from audiodec_amd.stream_generator import AutoEncoderStreamGenerator, HiFiGANStreamGenerator
+
+
+def test_assign_model_matches_reference_table():
+    sr, enc, dec = configs.assign_model("vctk_v1")
+    assert sr == 48000
+    assert enc == os.path.join("exp", "autoencoder", "symAD_vctk_48000_hop300", "checkpoint-200000steps.pkl")
+    assert dec == os.path.join("exp", "vocoder", "AudioDec_v1_symAD_vctk_48000_hop300_clean", "checkpoint-500000steps.pkl")
+    assert configs.assign_model("libritts_sym")[0] == 24000
+    assert len(configs._ALIASES) == 11
+    with pytest.raises(NotImplementedError, match="is not supported"):
+        configs.assign_model("vctk_v9")
+
+
+def test_parameter_counts_match_the_published_sizes():
+    # About/README.md:20-37 of the reference: enc 3,806,368 / dec 4,035,264 / v0 12,932,610 / v1 19,461,090 / v2 6,927,330
+    def count(specs):
+        n = 0
+        for s in specs:
+            n += int(np.prod(s.wshape)) + (s.wshape[0] if s.wn else 0) + (s.cout if s.bias else 0)
+        return n
+    _, _, p = configs.experiment("autoencoder/symAD_vctk_48000_hop300")
+    assert count(arch.autoencoder_encoder_convs(p)) == 3806368 + 98304 - 0      # encoder + projector (512*64*3)
+    assert count(arch.autoencoder_decoder_convs(p)) == 4035264
+    for tag, n in (("v0", 12932610), ("v1", 19461090), ("v2", 6927330)):
+        _, _, pv = configs.experiment(f"vocoder/AudioDec_{tag}_symAD_vctk_48000_hop300_clean")
+        assert count(arch.hifigan_convs(pv)) == n
+
+
+def test_history_lengths_follow_the_reference_formulas():
+    _, _, p = configs.experiment("autoencoder/symAD_vctk_48000_hop300")
+    by = arch.by_name(arch.autoencoder_encoder_convs(p) + arch.autoencoder_decoder_convs(p))
+    assert by["encoder.conv_blocks.0.res_units.2.conv1"].pad == 54          # (7-1)*9
+    assert by["encoder.conv_blocks.0.conv"].pad == 5                         # K=6, stride 3
+    assert by["decoder.conv_blocks.0.conv"].pad == 1                         # ceil(10/5)-1
+    assert by["projector.project"].pad == 2
+    assert arch.hop_length(p) == 300
+
+
+def test_synthetic_checkpoint_is_bit_reproducible():
+    """The golden fixtures are only valid for exactly these weights: pin their digest."""
+    sd = synth.synth_state_dict("autoencoder/symAD_vctk_48000_hop300", 1337)
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode()); h.update(sd[k].numpy().tobytes())
+    digest = h.hexdigest()
+    path = os.path.join(os.path.dirname(__file__), "golden", "synth_digest.txt")
+    if not os.path.exists(path):            # first run in the build container writes the pin
+        open(path, "w").write(digest + "\n")
+    assert open(path).read().strip() == digest
+    x = synth.synth_audio(1337, 0, 300)
+    assert x.dtype == np.float32 and np.abs(x).max() <= 1.0
+    assert np.array_equal(x, synth.synth_audio(1337, 0, 300))
+
+
+def test_lowering_flops_and_op_counts():
+    _, _, p = configs.experiment("autoencoder/symAD_vctk_48000_hop300")
+    sd = synth.synth_state_dict("autoencoder/symAD_vctk_48000_hop300")
+    enc = program.build_encoder(sd, p)
+    dec = program.build_sym_decoder(sd, p)
+    assert len(enc.ops) == 31 and len(dec.ops) == 31
+    assert enc.flops_per_frame == 81759488 and dec.flops_per_frame == 82021632
+    _, _, pv = configs.experiment("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean")
+    v1 = program.build_hifigan(synth.synth_state_dict("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean"), pv)
+    assert len(v1.ops) == 35 and v1.flops_per_frame == 596765952
+    # every ring's history covers its consumers; external rings carry none
+    for o in v1.ops:
+        if o.kind == 0:
+            assert v1.rings[o.in_ring]["hist"] >= o.conv.hist
+    assert all(r["hist"] == 0 for r in v1.rings if r["external"] >= 0)
+    # the x.repeat(1, 3, 1) of MultiGroupConv1d is never materialised
+    first = [o for o, n in zip(v1.ops, v1.op_names) if n == "blocks.0.convs1.0"][0]
+    assert first.conv.in_group_stride == 0 and first.conv.groups == 3 and v1.rings[first.in_ring]["channels"] == 256
+
+
+def test_transposed_conv_polyphase_packing():
+    torch.manual_seed(0)
+    cin, cout, s, T = 8, 4, 3, 6
+    w = torch.randn(cin, cout, 2 * s)
+    x = torch.randn(1, cin, T)
+    prev = torch.randn(1, cin, 1)
+    ref = torch.nn.functional.conv_transpose1d(torch.cat([prev, x], -1), w, None, stride=s)[:, :, s:-s]
+    rows = program.pack_convtr(w, s)                       # [(r*cout+co)][(j, ci)], tap 0 = x[t-1]
+    xx = torch.cat([prev, x], -1)[0]                       # (cin, T+1)
+    out = torch.zeros(cout, T * s)
+    for t in range(T):
+        col = torch.cat([xx[:, t], xx[:, t + 1]])
+        y = rows @ col
+        for r in range(s):
+            out[:, t * s + r] = y[r * cout:(r + 1) * cout]
+    assert torch.allclose(out, ref[0], atol=1e-5)
+
+
+def test_mfma_fragment_packing_layout():
+    groups, cout_g, ktot = 2, 96, 352
+    w = torch.arange(groups * cout_g * ktot, dtype=torch.float32).reshape(groups * cout_g, ktot)
+    p = program.pack_mfma(w, groups)
+    mt32, kg = 3, 384 // 8
+    assert p.numel() == groups * mt32 * kg * 256
+    for (g, mt, k8, lane, e) in [(0, 0, 0, 0, 0), (1, 2, 43, 37, 3), (0, 1, 44, 5, 0), (1, 0, 47, 63, 3)]:
+        row, k = 32 * mt + (lane & 31), 8 * k8 + 4 * (lane >> 5) + e
+        want = w[g * cout_g + row, k].item() if k < ktot else 0.0
+        assert p[(((g * mt32 + mt) * kg + k8) * 64 + lane) * 4 + e].item() == want
+
+
+def test_state_dict_loading_is_strict():
+    _, _, p = configs.experiment("autoencoder/symAD_vctk_48000_hop300")
+    m = AutoEncoderStreamGenerator(**p)
+    sd = synth.synth_state_dict("autoencoder/symAD_vctk_48000_hop300")
+    m.load_state_dict(sd)
+    bad = dict(sd); bad.pop("projector.project.conv.weight")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        AutoEncoderStreamGenerator(**p).load_state_dict(bad)
+    bad = dict(sd); bad["encoder.conv.conv.weight"] = torch.zeros(32, 1, 5)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        AutoEncoderStreamGenerator(**p).load_state_dict(bad)
+    with pytest.raises(TypeError):
+        AutoEncoderStreamGenerator(no_such_kw=1)
+    with pytest.raises(AssertionError):
+        AutoEncoderStreamGenerator(mode="noncausal")
+    _, _, pv = configs.experiment("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean")
+    HiFiGANStreamGenerator(**pv).load_state_dict(synth.synth_state_dict("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean"))

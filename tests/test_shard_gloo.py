@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the multi-GPU stream-sharding helpers (audiodec_amd/shard.py)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from audiodec_amd import shard
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard.stream_range(5)
+        assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
+        # rank 0's weights reach everyone bit for bit
+        g = torch.Generator().manual_seed(7 + rank)
+        sd = {"a.weight": torch.randn(4, 3, generator=g), "b.bias": torch.randn(5, generator=g)}
+        out = shard.broadcast_state_dict(sd, src=0)
+        g0 = torch.Generator().manual_seed(7)
+        assert torch.equal(out["a.weight"], torch.randn(4, 3, generator=g0)) and torch.equal(out["b.bias"], torch.randn(5, generator=g0))
+        # per-rank codes (n_q, B_local, T) gather to (n_q, B_total, T) on rank 0 in stream order
+        idx = torch.arange(8 * (hi - lo) * 2).reshape(8, hi - lo, 2) + 1000 * rank
+        allc = shard.gather_codes(idx, dst=0)
+        if rank == 0:
+            assert allc.shape == (8, 5, 2)
+            assert torch.equal(allc[:, :3], idx) and int(allc[0, 3, 0]) == 1000
+        else:
+            assert allc is None
+        assert shard.max_over_ranks(1.0 + rank, "cpu") == 2.0
+        q.put((rank, "ok"))
+    except Exception as e:          # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stream_sharding_over_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == {0: "ok", 1: "ok"}, res
+
+
+def test_stream_range_partitions_everything():
+    for n, w in ((2048, 8), (5, 2), (7, 3), (1, 4)):
+        seen = []
+        for r in range(w):
+            lo, hi = shard.stream_range(n, r, w)
+            seen += list(range(lo, hi))
+            for s in range(lo, hi):
+                assert shard.owner_of(s, n, w) == r
+        assert seen == list(range(n))
