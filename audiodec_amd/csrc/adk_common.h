@@ -38,8 +38,12 @@ __device__ __forceinline__ float act_apply(float x, int act, float slope) {
 }
 
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
-int launch_conv_mfma(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes);   // needs wfrag, cin_g % 32 == 0
-size_t conv_mfma_workspace_bytes();
+// scratch of the stream-K conv: partial accumulators of cut tiles + publish flags (zeroed once at
+// allocation; flags carry a per-launch epoch, so they are never reset)
+struct Workspace { float* ptr = nullptr; size_t bytes = 0; size_t flags_offset = 0; unsigned epoch = 0; };
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s, Workspace& ws);   // needs wfrag, cin_g % 32 == 0
+size_t conv_mfma_workspace_bytes(size_t* flags_offset);
+int* flags_word();                                   // device address of the sticky debug/error flags
 int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 bool conv_mfma_supported(const ConvArgs& a);
 int conv_mfma_pick(const ConvArgs& a);

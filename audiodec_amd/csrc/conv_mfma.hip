@@ -41,13 +41,17 @@ constexpr int KC = 64;    // K chunk: two 32-channel half-chunks (each one tap x
 constexpr int LDK = 68;   // padded LDS row stride (floats): conflict-free ds_write_b128 / ds_read_b128
 
 struct SkArgs {
-    float* ws;            // partial-tile workspace: [2*G][256 threads][NJ*16] floats
+    float* ws;            // partial-tile workspace: [G][256 threads][NJ*16] floats
+    unsigned* flags;      // [G] publish flags: flags[r] == epoch <=> range r's head partial is in ws
+    unsigned epoch;       // unique per launch on this workspace (never 0)
     int G;                // persistent workgroups (multiple of 8)
     int m_tiles, n_tiles, nchunks;
     int cpt;              // 32-channel blocks per tap = cin_g / 32
     int kgroups;          // 8-k fragments per 32-row m-tile, K zero-padded to a multiple of 64
     int mt32_per_g;       // 32-row fragment tiles per group
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents of the input arena view / packed weights
+    unsigned ws_bytes;            // extent of the partial workspace
+    int* err;                     // device error word (bit 1: a publish flag never arrived)
     float inv_t_out;
     long long total;      // tiles * nchunks
 };
@@ -243,7 +247,6 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     int tile = (int)(u0 / sk.nchunks);
     int kc = (int)(u0 - (long long)tile * sk.nchunks);
     int seg_start_kc = kc;                             // first chunk of the current segment
-    bool first_seg = true;                             // the segment that starts at u0
     stage_tile(tile, kc);
     gload();
     lstore(0);
@@ -291,70 +294,67 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         if (kc == sk.nchunks - 1 || !has_next) {
             const int ml0 = (cur_mt * WGM + wm) * 32;
             const int n0w = cur_nt * BN + wn * NJ * 32;
-            if (seg_start_kc == 0 && kc == sk.nchunks - 1) {
-                sk_epilogue<NJ>(a, acc, cur_g, ml0, n0w, lane);
-            } else {
-                // raw partial accumulators; slot 0 = the segment starting at u0, slot 1 = the other one
-                float* wsp = sk.ws + ((size_t)(2 * r + (first_seg ? 0 : 1)) * 256 + tid) * (NJ * 16);
+            const bool seg_first = (seg_start_kc == 0);            // segment holds the tile's first chunk
+            const bool seg_last = (kc == sk.nchunks - 1);          // ... and its last chunk
+            if (!seg_first) {
+                // Head of this range: the tile started in an earlier range, whose workgroup owns it.
+                // Publish the raw partial accumulators: write-through (sc1) stores, drain, one flag.
+                const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(sk.ws, 0, sk.ws_bytes, 0x00020000);
+                const unsigned wbase = ((unsigned)r * 256u + (unsigned)tid) * (unsigned)(NJ * 64);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4)
-                        *reinterpret_cast<float4*>(wsp + j * 16 + 4 * e4) =
-                            make_float4(acc[j][4 * e4], acc[j][4 * e4 + 1], acc[j][4 * e4 + 2], acc[j][4 * e4 + 3]);
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        u32x4 v;
+                        v.x = __float_as_uint(acc[j][4 * e4]); v.y = __float_as_uint(acc[j][4 * e4 + 1]);
+                        v.z = __float_as_uint(acc[j][4 * e4 + 2]); v.w = __float_as_uint(acc[j][4 * e4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)(j * 64 + e4 * 16), 0, 16 /* sc1 */);
+                    }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(sk.flags + r, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (!seg_last) {
+                    // Owner of a tile that continues in the following range(s): their head partials were
+                    // produced at the START of those workgroups' runs, this is the END of ours.  Add them in
+                    // range order (deterministic): one relaxed poll loop + one agent acquire per contributor.
+                    const long long t1 = ((long long)tile + 1) * sk.nchunks;
+                    for (int rr = r + 1; rr < sk.G && sk_u0(rr, sk) < t1; ++rr) {
+                        if (sk_u0(rr + 1, sk) <= sk_u0(rr, sk)) continue;       // empty range: publishes nothing
+                        if (tid == 0) {
+                            unsigned spins = 0;
+                            while (__hip_atomic_load(sk.flags + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                                __builtin_amdgcn_s_sleep(2);
+                                if (++spins > (1u << 20)) { atomicOr(sk.err, 2); break; }     // never hang the device
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        }
+                        __syncthreads();
+                        const float* wsp = sk.ws + ((size_t)rr * 256 + tid) * (NJ * 16);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const float4 v = *reinterpret_cast<const float4*>(wsp + j * 16 + 4 * e4);
+                                acc[j][4 * e4] += v.x; acc[j][4 * e4 + 1] += v.y; acc[j][4 * e4 + 2] += v.z; acc[j][4 * e4 + 3] += v.w;
+                            }
+                    }
+                }
+                sk_epilogue<NJ>(a, acc, cur_g, ml0, n0w, lane);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             seg_start_kc = 0;
-            first_seg = false;
             cur_g = s_g; cur_mt = s_mt; cur_nt = s_nt;   // staged tile = the next tile (if any)
         }
         __syncthreads();
         cur ^= 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) a_cur[q] = a_nxt[q];
-        if (++kc == sk.nchunks) kc = 0;
+        if (++kc == sk.nchunks) { kc = 0; ++tile; }
     }
-}
-
-// One workgroup per range boundary: if the boundary cuts a tile and is the FIRST cut inside that tile,
-// add the partial accumulators of all contributing ranges in range order and run the epilogue.
-template <int WGM, int WGN, int NJ>
-__global__ __launch_bounds__(256) void conv_sk_fixup_kernel(ConvArgs a, SkArgs sk) {
-    constexpr int BN = 32 * NJ * WGN;
-    const int rbd = blockIdx.x + 1;                    // boundary between range rbd-1 and rbd
-    const long long ub = sk_u0(rbd, sk);
-    if (ub >= sk.total || ub % sk.nchunks == 0) return;           // boundary falls between tiles
-    const int tile = (int)(ub / sk.nchunks);
-    const long long t0 = (long long)tile * sk.nchunks, t1 = t0 + sk.nchunks;
-    if (sk_u0(rbd - 1, sk) > t0) return;               // an earlier boundary also cuts this tile: it owns the fix-up
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    f32x16 acc[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    for (int rr = rbd - 1; rr < sk.G; ++rr) {
-        const long long s0 = sk_u0(rr, sk), s1 = sk_u0(rr + 1, sk);
-        if (s0 >= t1) break;
-        if (s1 <= s0) continue;
-        const long long lo = s0 > t0 ? s0 : t0;
-        const int slot = (lo == s0) ? 0 : 1;           // the segment that starts the range is slot 0
-        const float* wsp = sk.ws + ((size_t)(2 * rr + slot) * 256 + tid) * (NJ * 16);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const float4 v = *reinterpret_cast<const float4*>(wsp + j * 16 + 4 * e4);
-                acc[j][4 * e4] += v.x; acc[j][4 * e4 + 1] += v.y; acc[j][4 * e4 + 2] += v.z; acc[j][4 * e4 + 3] += v.w;
-            }
-    }
-    int g, mt, nt;
-    sk_tile_coords(tile, sk, g, mt, nt);
-    sk_epilogue<NJ>(a, acc, g, (mt * WGM + wm) * 32, nt * BN + wn * NJ * 32, lane);
 }
 
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
@@ -397,7 +397,7 @@ int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuri
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
 
 template <int WGM, int WGN, int NJ>
-int launch_cfg(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes) {
+int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN;
     constexpr size_t lds = 2ull * BN * LDK * sizeof(float);
     SkArgs sk;
@@ -420,9 +420,14 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes) {
     long long G = 256LL * g_occ;
     if (G > sk.total) G = (sk.total + 7) / 8 * 8;     // tiny problems: at most one unit per workgroup
     sk.G = (int)G;
-    sk.ws = ws;
-    const size_t need = (size_t)2 * sk.G * 256 * NJ * 16 * sizeof(float);
-    if (!ws || need > ws_bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
+    const size_t part_bytes = (size_t)sk.G * 256 * NJ * 16 * sizeof(float);
+    if (!ws.ptr || part_bytes + (size_t)sk.G * sizeof(unsigned) > ws.bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
+    sk.ws = ws.ptr;
+    sk.ws_bytes = (unsigned)part_bytes;
+    sk.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws.ptr) + ws.flags_offset);
+    sk.epoch = ++ws.epoch;
+    if (sk.epoch == 0) sk.epoch = ++ws.epoch;
+    sk.err = flags_word();
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -441,23 +446,18 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes) {
     else
         return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
     ADK_HIP_CHECK(hipGetLastError());
-    bool cut = false;                                  // does any range boundary fall inside a tile?
-    if (sk.nchunks == 1) cut = false;                  // one unit per tile: nothing to cut
-    else if (sk.total % sk.G == 0) cut = ((sk.total / sk.G) % sk.nchunks) != 0;
-    else cut = true;
-    if (cut && sk.G > 1) {
-        hipLaunchKernelGGL((conv_sk_fixup_kernel<WGM, WGN, NJ>), dim3(sk.G - 1), dim3(256), 0, s, a, sk);
-        ADK_HIP_CHECK(hipGetLastError());
-    }
     return ADK_OK;
 }
 }  // namespace
 
 void conv_mfma_force_cfg(int cfg) { g_forced_cfg = cfg; }
 
-size_t conv_mfma_workspace_bytes() {
+// workspace = partial slots [G][256][NJ<=4][16] floats, then G publish flags
+size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
     if (g_occ < 0) { const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2; }
-    return (size_t)2 * 256 * g_occ * 256 * 4 * 16 * sizeof(float);       // NJ <= 4
+    const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);
+    if (flags_offset) *flags_offset = part;
+    return part + (size_t)256 * g_occ * sizeof(unsigned);
 }
 
 int conv_mfma_pick(const ConvArgs& a) {
@@ -471,16 +471,16 @@ int conv_mfma_pick(const ConvArgs& a) {
 
 const char* conv_mfma_cfg_name(int pick) { return kCfgs[pick].name; }
 
-int launch_conv_mfma(const ConvArgs& a, hipStream_t s, float* ws, size_t ws_bytes) {
+int launch_conv_mfma(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (a.n_total == 0) return ADK_OK;
-    (void)conv_mfma_workspace_bytes();
+    (void)conv_mfma_workspace_bytes(nullptr);
     switch (conv_mfma_pick(a)) {
-        case 0: return launch_cfg<4, 1, 2>(a, s, ws, ws_bytes);
-        case 1: return launch_cfg<4, 1, 4>(a, s, ws, ws_bytes);
-        case 2: return launch_cfg<2, 2, 1>(a, s, ws, ws_bytes);
-        case 3: return launch_cfg<2, 2, 2>(a, s, ws, ws_bytes);
-        case 4: return launch_cfg<1, 4, 1>(a, s, ws, ws_bytes);
-        default: return launch_cfg<1, 4, 2>(a, s, ws, ws_bytes);
+        case 0: return launch_cfg<4, 1, 2>(a, s, ws);
+        case 1: return launch_cfg<4, 1, 4>(a, s, ws);
+        case 2: return launch_cfg<2, 2, 1>(a, s, ws);
+        case 3: return launch_cfg<2, 2, 2>(a, s, ws);
+        case 4: return launch_cfg<1, 4, 1>(a, s, ws);
+        default: return launch_cfg<1, 4, 2>(a, s, ws);
     }
 }
 

@@ -56,15 +56,16 @@ static int build_args(const adk_conv_desc& d, const adk_ring_view& in, const adk
     return ADK_OK;
 }
 
-struct Workspace { float* ptr = nullptr; size_t bytes = 0; };
 
 static int ensure_workspace(Workspace& w) {
-    const size_t need = conv_mfma_workspace_bytes();
+    size_t flags_offset = 0;
+    const size_t need = conv_mfma_workspace_bytes(&flags_offset);
     if (w.ptr && w.bytes >= need) return ADK_OK;
     if (w.ptr) (void)hipFree(w.ptr);
     w.ptr = nullptr; w.bytes = 0;
     ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&w.ptr), need));
-    w.bytes = need;
+    ADK_HIP_CHECK(hipMemset(w.ptr, 0, need));         // publish flags start below every epoch
+    w.bytes = need; w.flags_offset = flags_offset; w.epoch = 0;
     return ADK_OK;
 }
 
@@ -76,7 +77,7 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
     if (want_mfma) {
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
-        return launch_conv_mfma(a, s, ws.ptr, ws.bytes);
+        return launch_conv_mfma(a, s, ws);
     }
     // VALU kernel: Cin = 1 / Cout = 1 layers and anything the matrix-core kernel does not take
     if (!a.w) return fail(ADK_ERR_ARG, "conv: the VALU kernel needs row-major weights (w)");

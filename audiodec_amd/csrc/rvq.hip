@@ -9,7 +9,13 @@ namespace adk {
 
 constexpr int RVQ_DIM_MAX = 128;
 
-__device__ int g_adk_flags = 0;      // bit 0: rvq_lookup saw an out-of-range index
+__device__ int g_adk_flags = 0;      // bit 0: rvq_lookup saw an out-of-range index; bit 1: stream-K publish flag timeout
+
+int* flags_word() {
+    static int* p = nullptr;
+    if (!p) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_adk_flags));
+    return p;
+}
 
 // (value, index) arg-max with "greater value, else smaller index" -- matches `(-dist).max(1)` on the
 // reference's CPU path, which returns the lowest index among equal maxima.

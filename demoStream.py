@@ -3,15 +3,17 @@
 demoStream.py (/root/reference/demoStream.py:19-79).  Needs `sounddevice` at run time."""
 import argparse
 
+import torch
+
 from audiodec_amd.audiodec import AudioDec, AudioDecStreamer, assign_model
 
 
 def main():
     parser = argparse.ArgumentParser()
-    parser.add_argument("--model", type=str, default="libritts_v1")
+    parser.add_argument("--model", type=str, default="libritts_sym")
     parser.add_argument("-i", "--input", type=str, default="input.wav")
     parser.add_argument("-o", "--output", type=str, default="output.wav")
-    parser.add_argument("--tx_cuda", type=int, default=0)
+    parser.add_argument("--tx_cuda", type=int, default=0)   # reference default -1 (cpu); there is no CPU path here
     parser.add_argument("--rx_cuda", type=int, default=0)
     parser.add_argument("--input_device", type=int, default=1)
     parser.add_argument("--output_device", type=int, default=4)
@@ -21,6 +23,7 @@ def main():
 
     tx_device = "cpu" if args.tx_cuda < 0 else f"cuda:{args.tx_cuda}"
     rx_device = "cpu" if args.rx_cuda < 0 else f"cuda:{args.rx_cuda}"
+    torch.set_num_threads(args.num_threads)
 
     sample_rate, encoder_checkpoint, decoder_checkpoint = assign_model(args.model)
 

@@ -45,7 +45,9 @@ enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 };
 const char* adk_last_error(void);
 int adk_abi_version(void);
 /* sticky device-side flags since the last call (bit 0: adk_rvq_lookup saw an out-of-range index,
- * where F.embedding would raise); reading synchronises the device and clears them */
+ * where F.embedding would raise; bit 1: a stream-K conv workgroup gave up waiting for another
+ * workgroup's partial tile -- results of that launch are invalid); reading synchronises the device
+ * and clears them */
 int adk_debug_flags(int32_t* out);
 /* tuning hook: force the MFMA conv tile config (0..5), -1 = heuristic (also env ADK_CONV_CFG) */
 int adk_set_conv_cfg(int32_t cfg);
