@@ -319,17 +319,22 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                     // produced at the START of those workgroups' runs, this is the END of ours.  Add them in
                     // range order (deterministic): one relaxed poll loop + one agent acquire per contributor.
                     const long long t1 = ((long long)tile + 1) * sk.nchunks;
-                    for (int rr = r + 1; rr < sk.G && sk_u0(rr, sk) < t1; ++rr) {
-                        if (sk_u0(rr + 1, sk) <= sk_u0(rr, sk)) continue;       // empty range: publishes nothing
-                        if (tid == 0) {
+                    int rr_end = r + 1;
+                    while (rr_end < sk.G && sk_u0(rr_end, sk) < t1) ++rr_end;
+                    if (tid == 0) {                                // wait for ALL contributors, then one acquire
+                        for (int rr = r + 1; rr < rr_end; ++rr) {
+                            if (sk_u0(rr + 1, sk) <= sk_u0(rr, sk)) continue;   // empty range: publishes nothing
                             unsigned spins = 0;
                             while (__hip_atomic_load(sk.flags + rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
                                 __builtin_amdgcn_s_sleep(2);
                                 if (++spins > (1u << 20)) { atomicOr(sk.err, 2); break; }     // never hang the device
                             }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         }
-                        __syncthreads();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    for (int rr = r + 1; rr < rr_end; ++rr) {
+                        if (sk_u0(rr + 1, sk) <= sk_u0(rr, sk)) continue;
                         const float* wsp = sk.ws + ((size_t)rr * 256 + tid) * (NJ * 16);
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
@@ -395,6 +400,7 @@ const Cfg kCfgs[6] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"
                       {2, 2, 2, "conv_sk<64x128>"}, {1, 4, 1, "conv_sk<32x128>"}, {1, 4, 2, "conv_sk<32x256>"}};
 int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
+int g_min_units = 2;       // minimum K chunks per workgroup (ADK_CONV_MIN_UNITS; 2 measured best at 256 streams)
 
 template <int WGM, int WGN, int NJ>
 int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
@@ -417,8 +423,11 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     }
     const long long tiles = (long long)sk.m_tiles * sk.n_tiles * a.groups;
     sk.total = tiles * sk.nchunks;
+    // persistent workgroups: 256 CUs x occupancy, but never fewer than g_min_units chunks per workgroup
+    // (each one pays a fixed prologue/epilogue, and every cut of a tile costs a partial round trip)
     long long G = 256LL * g_occ;
-    if (G > sk.total) G = (sk.total + 7) / 8 * 8;     // tiny problems: at most one unit per workgroup
+    const long long by_units = (sk.total + g_min_units - 1) / g_min_units;
+    if (G > by_units) G = (by_units + 7) / 8 * 8;
     sk.G = (int)G;
     const size_t part_bytes = (size_t)sk.G * 256 * NJ * 16 * sizeof(float);
     if (!ws.ptr || part_bytes + (size_t)sk.G * sizeof(unsigned) > ws.bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
@@ -454,7 +463,10 @@ void conv_mfma_force_cfg(int cfg) { g_forced_cfg = cfg; }
 
 // workspace = partial slots [G][256][NJ<=4][16] floats, then G publish flags
 size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
-    if (g_occ < 0) { const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2; }
+    if (g_occ < 0) {
+        const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2;
+        e = getenv("ADK_CONV_MIN_UNITS"); if (e && atoi(e) >= 1) g_min_units = atoi(e);
+    }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);
     if (flags_offset) *flags_offset = part;
     return part + (size_t)256 * g_occ * sizeof(unsigned);

@@ -235,6 +235,40 @@ def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
     assert np.array_equal(one[1], again[1]) and np.array_equal(one[0], again[0]) and np.array_equal(one[3], again[3])
 
 
+def test_transmitter_receiver_on_two_hip_streams(gpu, ckpt_root):
+    """bench.py's schedule: encode+RVQ on one HIP stream, lookup+vocoder on another, codes handed over by an
+    event (the reference's two streamer threads).  Concurrent stream-K kernels must not disturb each other."""
+    seed, B, hop, steps = 77, 24, 300, 6
+    audio = np.stack([synth.synth_audio(seed, s, steps * hop) for s in range(B)])
+    ad = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 1)
+    s_tx, s_rx = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    ys, idxs = [], []
+    with torch.no_grad():
+        xs = [torch.from_numpy(audio[:, i * hop:(i + 1) * hop])[:, None, :].to(DEV) for i in range(steps)]
+        torch.cuda.synchronize()
+        for i in range(steps):
+            with torch.cuda.stream(s_tx):
+                idx = ad.tx_encoder.quantize(ad.tx_encoder.encode(xs[i]))
+                ev = torch.cuda.Event(); ev.record(s_tx)
+            with torch.cuda.stream(s_rx):
+                s_rx.wait_event(ev)
+                idx.record_stream(s_rx)
+                ys.append(ad.decoder.decode(ad.rx_encoder.lookup(idx))); idxs.append(idx)
+        torch.cuda.synchronize()
+    y = torch.cat(ys, -1).cpu().numpy(); idx = torch.cat(idxs, -1).cpu().numpy()
+    tx, rx, dec = build_oracle("vctk_v1", B, 1337)
+    with torch.no_grad():
+        oi, om = tx.quantize(tx.encode(torch.from_numpy(audio)[:, None, :]), return_margin=True)
+        oy = dec.decode(rx.lookup(oi))
+    explain_flips(idx, oi.numpy(), om.numpy(), "two-stream vctk_v1")
+    assert np.abs(y - oy.numpy()).max() < WAVE_TOL
+    from audiodec_amd import native
+    import ctypes
+    f = ctypes.c_int32(0)
+    native.check(native.lib().adk_debug_flags(ctypes.byref(f)), "adk_debug_flags")
+    assert f.value == 0, "a stream-K workgroup timed out waiting for a partial tile"
+
+
 def test_error_behaviour(gpu, ckpt_root):
     from audiodec_amd.audiodec import AudioDec, assign_model
     from audiodec_amd import native
