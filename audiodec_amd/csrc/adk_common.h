@@ -37,6 +37,12 @@ __device__ __forceinline__ float act_apply(float x, int act, float slope) {
     return x;
 }
 
+struct RingMeanArgs {
+    const float* src[4]; int src_rows[4], src_cursor[4];
+    float* out; int out_rows, out_cursor;
+    int n, channels, batch, t;
+};
+int launch_ring_mean(const RingMeanArgs& m, hipStream_t s);
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 // scratch of the stream-K conv: partial accumulators of cut tiles + publish flags (zeroed once at
 // allocation; flags carry a per-launch epoch, so they are never reset)

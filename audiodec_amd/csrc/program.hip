@@ -178,6 +178,13 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             if (!ring_ok(o.out_ring) || o.ext_src < 0) return bail(ADK_ERR_ARG, "program_create: ring_write needs out_ring and ext_src");
             if (o.ext_src + 1 > p->n_ext) p->n_ext = o.ext_src + 1;
             if ((o.mean_off >= 0) != (o.scale_off >= 0)) return bail(ADK_ERR_ARG, "program_create: mean and scale go together");
+        } else if (o.kind == ADK_OP_MEAN) {
+            if (!ring_ok(o.out_ring) || o.n_mean < 1 || o.n_mean > 4) return bail(ADK_ERR_ARG, "program_create: mean needs out_ring and 1..4 sources");
+            for (int k = 0; k < o.n_mean; ++k) {
+                if (!ring_ok(o.mean_rings[k])) return bail(ADK_ERR_ARG, "program_create: mean references an unknown ring");
+                if (rings[o.mean_rings[k]].channels != rings[o.out_ring].channels || rings[o.mean_rings[k]].rate != rings[o.out_ring].rate)
+                    return bail(ADK_ERR_SHAPE, "program_create: mean sources must match the output ring");
+            }
         } else {
             return bail(ADK_ERR_ARG, "program_create: unknown op kind");
         }
@@ -239,6 +246,18 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
             int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
             if (rc == ADK_OK) rc = run_conv(a, o.impl, s, p->ws);
             if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+        } else if (o.kind == ADK_OP_MEAN) {
+            RingMeanArgs m;
+            memset(&m, 0, sizeof(m));
+            adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
+            m.out = out.base; m.out_rows = out.rows; m.out_cursor = out.cursor;
+            m.n = o.n_mean; m.channels = out.channels; m.batch = p->batch; m.t = frames * p->rings[o.out_ring].rate;
+            for (int k = 0; k < o.n_mean; ++k) {
+                adk_ring_view sv = view_of(p, o.mean_rings[k], frames, ext, 0);
+                m.src[k] = sv.base; m.src_rows[k] = sv.rows; m.src_cursor[k] = sv.cursor;
+            }
+            int rc = launch_ring_mean(m, s);
+            if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
         } else {
             adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
             const float* mean = o.mean_off >= 0 ? p->weights + o.mean_off : nullptr;
@@ -258,7 +277,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
 extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frames, char* buf, int32_t n) {
     if (!p || !buf || n <= 0 || op < 0 || op >= (int)p->ops.size()) return fail(ADK_ERR_ARG, "program_describe_op: bad arguments");
     const adk_op_desc& o = p->ops[op];
-    std::string name = "ring_write";
+    std::string name = o.kind == ADK_OP_MEAN ? "ring_mean" : "ring_write";
     if (o.kind == ADK_OP_CONV) {
         adk_conv_desc d = o.conv;
         d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;

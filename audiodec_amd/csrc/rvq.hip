@@ -158,6 +158,35 @@ __global__ __launch_bounds__(256) void ring_write_kernel(const float* __restrict
     }
 }
 
+// out[b][t][c] = (((s0 + s1) + s2) ...) / n  -- the reference accumulates cs = 0.0; cs += y_i; c = cs / n
+__global__ __launch_bounds__(256) void ring_mean_kernel(RingMeanArgs m) {
+    const long long total = (long long)m.batch * m.t * m.channels;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % m.channels);
+        const long long bt = gid / m.channels;
+        const int tt = (int)(bt % m.t), b = (int)(bt / m.t);
+        float acc = 0.f;
+        for (int i = 0; i < m.n; ++i) {
+            int row = m.src_cursor[i] + tt;
+            if (row >= m.src_rows[i]) row -= m.src_rows[i];
+            acc = __fadd_rn(acc, m.src[i][((size_t)b * m.src_rows[i] + row) * m.channels + c]);
+        }
+        int orow = m.out_cursor + tt;
+        if (orow >= m.out_rows) orow -= m.out_rows;
+        m.out[((size_t)b * m.out_rows + orow) * m.channels + c] = __fdiv_rn(acc, (float)m.n);
+    }
+}
+
+int launch_ring_mean(const RingMeanArgs& m, hipStream_t s) {
+    const long long total = (long long)m.batch * m.t * m.channels;
+    if (total == 0) return ADK_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ring_mean_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
 }  // namespace adk
 
 using namespace adk;

@@ -9,12 +9,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaudiodec_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
-OP_CONV, OP_RING_WRITE = 0, 1
+OP_CONV, OP_RING_WRITE, OP_MEAN = 0, 1, 2
 
 
 class RingView(C.Structure):
@@ -40,7 +40,8 @@ class OpDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_ring", C.c_int32), ("out_ring", C.c_int32), ("res_ring", C.c_int32),
                 ("in_ch_off", C.c_int32), ("out_ch_off", C.c_int32), ("res_ch_off", C.c_int32),
                 ("rate_out", C.c_int32), ("conv", ConvDesc), ("w_off", C.c_int64), ("wf_off", C.c_int64), ("b_off", C.c_int64),
-                ("mean_off", C.c_int64), ("scale_off", C.c_int64), ("ext_src", C.c_int32), ("impl", C.c_int32)]
+                ("mean_off", C.c_int64), ("scale_off", C.c_int64), ("ext_src", C.c_int32),
+                ("mean_rings", C.c_int32 * 4), ("n_mean", C.c_int32), ("impl", C.c_int32)]
 
 
 # every symbol include/audiodec_hip.h declares: (restype, argtypes)

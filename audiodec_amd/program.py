@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import arch, native
-from .native import (ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_TANH, IMPL_AUTO, OP_CONV, OP_RING_WRITE,
+from .native import (ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_TANH, IMPL_AUTO, OP_CONV, OP_MEAN, OP_RING_WRITE,
                      ConvDesc, OpDesc, RingDesc)
 
 
@@ -135,6 +135,20 @@ class Builder:
         op.rate_out = self.rings[out_ring]["rate"]
         self.ops.append(op)
         self.op_names.append("ring_write")
+
+    def mean(self, src_rings, out_ring):
+        """out = (((s0 + s1) + s2) ...) / n   (MultiReceptiveField, multi_fusion.py:73-79)"""
+        op = OpDesc()
+        op.kind = OP_MEAN
+        op.in_ring, op.out_ring, op.res_ring = -1, out_ring, -1
+        op.w_off, op.wf_off, op.b_off, op.mean_off, op.scale_off = -1, -1, -1, -1, -1
+        op.ext_src = -1
+        op.n_mean = len(src_rings)
+        for k, r in enumerate(src_rings):
+            op.mean_rings[k] = r
+        op.rate_out = self.rings[out_ring]["rate"]
+        self.ops.append(op)
+        self.op_names.append("mean")
 
     def conv(self, name, in_ring, out_ring, act_in=ACT_NONE, slope=0.0, act_out=ACT_NONE, res_ring=-1,
              in_group_stride=None, res_group_stride=None, impl=IMPL_AUTO):
@@ -264,12 +278,12 @@ def build_hifigan(sd, p):
     specs = arch.hifigan_convs(p)
     b = Builder(sd, specs)
     act, slope = _act_of(p, "LeakyReLU")
-    if not arch.hifigan_is_multigroup(p):
-        raise NotImplementedError("MultiReceptiveField vocoder (AudioDec v0) is not lowered yet")
+    multigroup = arch.hifigan_is_multigroup(p)
     groups = p.get("groups", 1)
     ch = p.get("channels", 512)
-    n_layer = len(p["resblock_dilations"][0])
     addl = p.get("use_additional_convs", True)
+    if not addl:
+        raise NotImplementedError("use_additional_convs=False is not lowered")
     rate = 1
     rz = b.ring(p["in_channels"], 0, rate)
     norm = "mean" in sd
@@ -280,20 +294,33 @@ def build_hifigan(sd, p):
     for i, s in enumerate(p["upsample_scales"]):
         c = ch // (2 ** (i + 1))
         rate *= s
-        x = b.ring(c, 0, rate)                                  # block input, un-repeated
-        b.conv(f"upsamples.{i}", cur, x, act, slope)            # upsamples[i].inference(act(c))
-        gs_in, gs_res = 0, 0                                    # first layer reads x.repeat(1, groups, 1)
-        for j in range(n_layer):
-            xt = b.ring(c * groups, 0, rate)
-            b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
-            if addl:
+        x0 = b.ring(c, 0, rate)                                 # block input, un-repeated
+        b.conv(f"upsamples.{i}", cur, x0, act, slope)           # upsamples[i].inference(act(c))
+        cur = b.ring(c, 0, rate)
+        if multigroup:
+            # MultiGroupConv1d.inference (multi_fusion.py:133-141): x.repeat(1, groups, 1) is never
+            # materialised -- the first conv and the first residual read the same C channels per group
+            x, gs_in, gs_res = x0, 0, 0
+            for j in range(len(p["resblock_dilations"][0])):
+                xt = b.ring(c * groups, 0, rate)
+                b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
                 nx = b.ring(c * groups, 0, rate)
                 b.conv(f"blocks.{i}.convs2.{j}", xt, nx, act, slope, res_ring=x, res_group_stride=gs_res)
-            else:
-                raise NotImplementedError("use_additional_convs=False is not lowered yet")
-            x, gs_in, gs_res = nx, None, None
-        cur = b.ring(c, 0, rate)
-        b.conv(f"blocks.{i}.conv_out", x, cur)
+                x, gs_in, gs_res = nx, None, None
+            b.conv(f"blocks.{i}.conv_out", x, cur)
+        else:
+            # MultiReceptiveField.inference (multi_fusion.py:73-79): mean of the residual blocks, all fed by x0
+            outs = []
+            for bi, dil in enumerate(p["resblock_dilations"]):
+                x = x0
+                for j in range(len(dil)):
+                    xt = b.ring(c, 0, rate)
+                    b.conv(f"blocks.{i}.blocks.{bi}.convs1.{j}", x, xt, act, slope)
+                    nx = b.ring(c, 0, rate)
+                    b.conv(f"blocks.{i}.blocks.{bi}.convs2.{j}", xt, nx, act, slope, res_ring=x)
+                    x = nx
+                outs.append(x)
+            b.mean(outs, cur)
     y = b.ring(p.get("out_channels", 1), 0, rate, external=1)
     # activation_output1 = nn.LeakyReLU() default slope 0.01 (HiFiGAN.py:116); tanh after (:117)
     b.conv("output_conv", cur, y, ACT_LEAKY, 0.01, ACT_TANH)

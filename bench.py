@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no transmitter/receiver overlap)")
+    ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently stepped groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-profile", action="store_true")
     ap.add_argument("--dump-ops", type=str, default=None, help="write the per-op HIP-event table (CSV) here")
@@ -210,7 +211,10 @@ def main():
     sr, _, tx_steps, _, rx_steps = configs.alias(MODEL)
     synth.write_experiment(tmp.name, enc_tag, tx_steps, SEED, sd=sds[enc_tag])
     synth.write_experiment(tmp.name, dec_tag, rx_steps, SEED, sd=sds[dec_tag])
-    ad = build_audiodec(tmp.name, dev, B, 1)
+    NG = args.groups
+    assert B % NG == 0
+    ads = [build_audiodec(tmp.name, dev, B // NG, 1) for _ in range(NG)]
+    ad = ads[0]
 
     lo, hi = rank * B, (rank + 1) * B            # global stream ids of this rank
     n_buf = 8
@@ -223,7 +227,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    pipe = None if args.serial else TxRxPipeline(ad, dev)
+    if NG > 1:
+        pipes = [TxRxPipeline(a_, dev) for a_ in ads]
+        Bg = B // NG
+
+        class _Multi:
+            def enter(self):
+                for p_ in pipes: p_.enter()
+            def exit(self):
+                for p_ in pipes: p_.exit()
+            def step(self, x):
+                return [p_.step(x[g * Bg:(g + 1) * Bg]) for g, p_ in enumerate(pipes)]
+        pipe = _Multi()
+    else:
+        pipe = None if args.serial else TxRxPipeline(ad, dev)
     run = (lambda x: step(ad, x)) if pipe is None else pipe.step
     with torch.no_grad():
         if pipe:
@@ -268,14 +285,15 @@ def main():
         for i in range(12):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            step(ad, xs[i % n_buf])
+            for g_, a_ in enumerate(ads):
+                step(a_, xs[i % n_buf][g_ * (B // NG):(g_ + 1) * (B // NG)])
             torch.cuda.synchronize()
             lat.append(1e3 * (time.perf_counter() - t1))
     out["latency_ms"]["encode_decode_at_batch_median"] = round(float(np.median(lat[2:])), 4)
 
     if rank == 0 and world == 1:
         with torch.no_grad():
-            if not args.no_op_profile:
+            if not args.no_op_profile and NG == 1:
                 rows = op_profile(ad, xs, B, 10)
                 if args.dump_ops:
                     with open(args.dump_ops, "w") as f:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 2
+#define ADK_ABI_VERSION 3
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -151,7 +151,7 @@ typedef struct {
     int64_t arena_off;   /* float offset of this ring in the arena (batch * rows * channels floats)  */
 } adk_ring_desc;
 
-enum { ADK_OP_CONV = 0, ADK_OP_RING_WRITE = 1 };
+enum { ADK_OP_CONV = 0, ADK_OP_RING_WRITE = 1, ADK_OP_MEAN = 2 };
 
 typedef struct {
     int32_t kind;                        /* ADK_OP_*                                                  */
@@ -163,6 +163,10 @@ typedef struct {
                                             weights, bias); < 0: absent (at least one of w_off / wf_off)     */
     int64_t mean_off, scale_off;         /* ADK_OP_RING_WRITE: offsets of mean/scale, < 0: none       */
     int32_t ext_src;                     /* ADK_OP_RING_WRITE: index into ext[] of the source rows    */
+    int32_t mean_rings[4];               /* ADK_OP_MEAN: out = (((r0 + r1) + r2) ...) / n over n_mean source rings
+                                            (MultiReceptiveField: cs += block(c); c = cs / num_blocks,
+                                            models/vocoder/modules/multi_fusion.py:73-79)              */
+    int32_t n_mean;
     int32_t impl;                        /* ADK_IMPL_*                                                */
 } adk_op_desc;
 

@@ -156,7 +156,7 @@ def run_hip(ad, audio, chunks):
 
 
 @pytest.mark.parametrize("name,max_frames", [("vctk_sym_stream", 2), ("vctk_v1_stream", 4), ("libritts_sym_file", 16),
-                                             ("vctk_v2_stream", 2), ("vctk_activate_sym_stream", 2),
+                                             ("vctk_v2_stream", 2), ("vctk_v0_stream", 2), ("vctk_activate_sym_stream", 2),
                                              ("vctk_c16h320_sym_stream", 2)])
 def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames):
     g = _load(golden_dir, name)

@@ -73,6 +73,10 @@ def test_lowering_flops_and_op_counts():
     _, _, pv = configs.experiment("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean")
     v1 = program.build_hifigan(synth.synth_state_dict("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean"), pv)
     assert len(v1.ops) == 35 and v1.flops_per_frame == 596765952
+    _, _, p0 = configs.experiment("vocoder/AudioDec_v0_symAD_vctk_48000_hop300_clean")
+    v0 = program.build_hifigan(synth.synth_state_dict("vocoder/AudioDec_v0_symAD_vctk_48000_hop300_clean"), p0)
+    assert len(v0.ops) == 1 + 78 + 4 and v0.op_names.count("mean") == 4                # MRF: mean of 3 resblocks per stage
+    assert v0.flops_per_frame == 2 * 189326976                                          # 189.3 M MAC
     # every ring's history covers its consumers; external rings carry none
     for o in v1.ops:
         if o.kind == 0:
