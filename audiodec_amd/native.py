@@ -57,6 +57,10 @@ SYMBOLS = {
     "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),
     "adk_rvq_encode": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "adk_rvq_lookup": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "adk_codes_frame_bytes": (C.c_int32, [_i32, _i32]),
+    "adk_codes_pack": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "adk_codes_unpack": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "adk_codes_lookup": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "adk_program_create": (C.c_int, [C.POINTER(OpDesc), _i32, C.POINTER(RingDesc), _i32, _i32, _i32, _vp, _i64,
                                      _vp, _i64, C.POINTER(_vp)]),
     "adk_program_destroy": (None, [_vp]),

@@ -405,6 +405,39 @@ class HipProgram:
         native.check(self.lib.adk_program_describe_op(self.h, op, frames, buf, 64), "adk_program_describe_op")
         return buf.value.decode()
 
+    # ---- per-stream state (multi-stream serving: one stream joins / leaves / is reset, the others run on) ----
+    def _ring_view(self, i):
+        m = self.ring_meta[i]
+        n = self.batch * m["rows"] * m["channels"]
+        return self.arena[m["arena_off"]:m["arena_off"] + n].view(self.batch, m["rows"], m["channels"])
+
+    def capture_stream_state(self, b=0):
+        """History rows of stream b, oldest first, per ring: what the reference calls the pad_buffers.
+        Cursors only ever advance by whole frames, so the rows in front of the cursor keep their phase
+        and the capture can be restored later at a different cursor."""
+        cur = self.cursors()
+        out = []
+        for i, m in enumerate(self.ring_meta):
+            if m["external"] >= 0 or m["hist"] == 0:
+                out.append(None)
+                continue
+            rows = (cur[i] - m["hist"] + torch.arange(m["hist"], device=self.dev)) % m["rows"]
+            out.append(self._ring_view(i)[b, rows].clone())
+        return out
+
+    def restore_stream_state(self, b, state):
+        """Overwrite stream b's history with a captured state (state=None: zeros = reset_buffer for that stream)."""
+        cur = self.cursors()
+        for i, m in enumerate(self.ring_meta):
+            if m["external"] >= 0 or m["hist"] == 0:
+                continue
+            rows = (cur[i] - m["hist"] + torch.arange(m["hist"], device=self.dev)) % m["rows"]
+            v = self._ring_view(i)
+            if state is None:
+                v[b, rows] = 0.0
+            else:
+                v[b, rows] = state[i]
+
     def set_profiling(self, on):
         native.check(self.lib.adk_program_set_profiling(self.h, 1 if on else 0), "adk_program_set_profiling")
 

@@ -51,6 +51,7 @@ class _StreamBase:
         self._device = None
         self.num_streams = 1
         self.max_frames = 16
+        self._warm = {}
 
     # ---- torch.nn.Module surface the reference's loader touches (bin/stream.py:59-61) ----
     def eval(self):
@@ -75,6 +76,22 @@ class _StreamBase:
 
     def _expected_keys(self):
         raise NotImplementedError
+
+    def _programs(self):
+        return {}
+
+    def reset_stream(self, b, warm=True):
+        """Put stream `b` back into the warmed-up state left by initial_encoder / initial_decoder
+        (warm=True) or into the all-zero state of reset_buffer() (warm=False); the other streams keep
+        running.  (The reference has one stream per object and can only reset everything.)"""
+        if not 0 <= b < self.num_streams:
+            raise IndexError(f"stream {b} out of range 0..{self.num_streams - 1}")
+        for name, prog in self._programs().items():
+            if prog is not None:
+                prog.restore_stream_state(b, self._warm.get(name) if warm else None)
+
+    def _capture_warm(self, name, prog):
+        self._warm[name] = prog.capture_stream_state(0)
 
     def load_state_dict(self, state_dict, strict=True):
         exp = self._expected_keys()
@@ -165,6 +182,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
     def _drop_programs(self):
         self._enc = self._dec = None
         self._embed = self._enorm = self._codebook = None
+        self._warm = {}
 
     def _expected_keys(self):
         p = self.params
@@ -212,11 +230,16 @@ class AutoEncoderStreamGenerator(_StreamBase):
         self.initial()
         frames = math.ceil(receptive_length / self.hop)
         z = self.encode(torch.zeros(self.num_streams, self.input_channels, frames * self.hop, device=self._dev()))
+        self._capture_warm("enc", self._encoder())
         idx = self.quantize(z[:1])
         return self.lookup(idx)
 
     def initial_decoder(self, zq):
         self.decode(zq)                                        # AudioDec.py:224-225
+        self._capture_warm("dec", self._decoder())
+
+    def _programs(self):
+        return {"enc": self._enc, "dec": self._dec}
 
     def encode(self, x):
         """(B, C, L) -> z (B', code_dim, ceil(L/hop))   (AudioDec.py:228-234)."""
@@ -269,6 +292,23 @@ class AutoEncoderStreamGenerator(_StreamBase):
             B * T, n_q, self.dim, self._codebook.shape[0], native.current_stream(dev)), "adk_rvq_lookup")
         return zq
 
+    # ---- bit-packed transport (audiodec_amd/wire.py; the reference has no wire format) ----
+    def pack(self, idx):
+        """Emitted indices -> uint8 payload (B, T, n_q*bits/8): 10 bytes per frame for 8 x 1024 codes."""
+        from . import wire
+        return wire.pack_codes(idx.to(self._dev()), self.size)
+
+    def unpack(self, payload):
+        from . import wire
+        return wire.unpack_codes(payload.to(self._dev()), self.n_q, self.size)
+
+    def lookup_packed(self, payload):
+        """payload -> zq (B, T, code_dim): unpack fused into the codebook lookup."""
+        from . import wire
+        if self._codebook is None:
+            self.initial()
+        return wire.lookup_packed(payload.to(self._dev()), self._codebook, self.n_q, self.size)
+
     def decode(self, zq):
         """zq (B, T, code_dim) -> y (B, out_channels, T*hop)  (AudioDec.py:246-247)."""
         return _decode_common(self, self._decoder(), zq, self.dim, self.hop)
@@ -313,6 +353,7 @@ class HiFiGANStreamGenerator(_StreamBase):
 
     def _drop_programs(self):
         self._dec = None
+        self._warm = {}
 
     def _expected_keys(self):
         exp = self._conv_keys(arch.hifigan_convs(self.params))
@@ -329,6 +370,10 @@ class HiFiGANStreamGenerator(_StreamBase):
 
     def initial_decoder(self, c):
         self.decode(c)                                         # HiFiGAN.py:264-265
+        self._capture_warm("dec", self._decoder())
+
+    def _programs(self):
+        return {"dec": self._dec}
 
     def decode(self, c):
         """c (B, T, in_channels) -> (B, 1, T*hop): norm, input conv, upsample stack, output conv, tanh

@@ -46,7 +46,8 @@ const char* adk_last_error(void);
 int adk_abi_version(void);
 /* sticky device-side flags since the last call (bit 0: adk_rvq_lookup saw an out-of-range index,
  * where F.embedding would raise; bit 1: a stream-K conv workgroup gave up waiting for another
- * workgroup's partial tile -- results of that launch are invalid); reading synchronises the device
+ * workgroup's partial tile -- results of that launch are invalid; bit 2: adk_codes_pack saw an index that
+ * is not a code of its stage); reading synchronises the device
  * and clears them */
 int adk_debug_flags(int32_t* out);
 /* tuning hook: force the MFMA conv tile config (0..5), -1 = heuristic (also env ADK_CONV_CFG) */
@@ -134,6 +135,21 @@ int adk_rvq_encode(const float* z, const float* embed, const float* enorm, int64
  */
 int adk_rvq_lookup(const int64_t* idx, const float* codebook, float* zq,
                    int32_t n_rows, int32_t n_q, int32_t dim, int32_t n_codes, void* stream);
+
+/*
+ * Bit-packed code wire format (the reference passes the int64 index tensor through a
+ * queue.Queue, bin/stream.py:224,230, and never serialises it).  One frame of one stream = n_q codes of
+ * `bits` bits, LSB-first: code q (= emitted index - size*q) occupies bits [q*bits, (q+1)*bits) of the
+ * adk_codes_frame_bytes(n_q, bits) = ceil(n_q*bits/8) byte frame; 8 x 10 bit = 10 bytes = 12.8 kbps at
+ * 160 frames/s.  idx is [n_q][n_rows] int64 as emitted by adk_rvq_encode; payload is [n_rows][frame_bytes].
+ * adk_codes_lookup = unpack fused into ResidualVQ.lookup (layers/vq_module.py:159-161).
+ * A code >= size raises adk_debug_flags bit 2 (pack) / bit 0 (lookup, reads code 0).
+ */
+int32_t adk_codes_frame_bytes(int32_t n_q, int32_t bits);
+int adk_codes_pack(const int64_t* idx, uint8_t* payload, int32_t n_rows, int32_t n_q, int32_t bits, int32_t size, void* stream);
+int adk_codes_unpack(const uint8_t* payload, int64_t* idx, int32_t n_rows, int32_t n_q, int32_t bits, int32_t size, void* stream);
+int adk_codes_lookup(const uint8_t* payload, const float* codebook, float* zq, int32_t n_rows, int32_t n_q, int32_t bits,
+                     int32_t size, int32_t dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pipeline level: a "program" is the fixed launch sequence of one model half (encoder+projector,

@@ -282,3 +282,70 @@ def test_error_behaviour(gpu, ckpt_root):
     ad = load_audiodec(ckpt_root, "vctk_sym", 1337, 2, 2)
     with pytest.raises(ValueError):
         ad.tx_encoder.encode(torch.zeros(3, 1, 300, device=DEV))      # wrong stream count
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" rows: wire format and the batched multi-stream streamer
+# ------------------------------------------------------------------------------------------------
+def test_wire_format_matches_oracle_bit_for_bit(gpu):
+    from audiodec_amd import wire
+    from oracle import wire_oracle as W
+    gold_idx, gold_payload = W.make_wire_golden()
+    p = wire.pack_codes(torch.from_numpy(gold_idx).to(gpu), 1024)
+    assert np.array_equal(p.cpu().numpy()[0], gold_payload)
+    rng = np.random.default_rng(5)
+    for n_q, size, B, T in ((8, 1024, 7, 13), (16, 1024, 3, 5), (8, 512, 2, 9), (3, 1000, 4, 4)):
+        bits = wire.code_bits(size)
+        idx = rng.integers(0, size, (n_q, B, T)) + size * np.arange(n_q)[:, None, None]
+        pay = wire.pack_codes(torch.from_numpy(idx).to(gpu), size)
+        ref = W.pack(idx.reshape(n_q, B * T), bits, size).reshape(B, T, -1)
+        assert pay.shape == ref.shape and np.array_equal(pay.cpu().numpy(), ref)
+        back = wire.unpack_codes(pay, n_q, size).cpu().numpy().reshape(n_q, B, T)
+        assert np.array_equal(back, idx)
+    # edge: empty batch of frames
+    assert wire.pack_codes(torch.zeros(8, 1, 0, dtype=torch.int64, device=gpu)).shape == (1, 0, 10)
+
+
+def test_packed_lookup_equals_lookup(gpu, ckpt_root):
+    ad = load_audiodec(ckpt_root, "vctk_sym", 1337, 4, 2)
+    x = torch.from_numpy(np.stack([synth.synth_audio(3, s, 600) for s in range(4)]))[:, None, :].to(gpu)
+    idx = ad.tx_encoder.quantize(ad.tx_encoder.encode(x))
+    payload = ad.tx_encoder.pack(idx)
+    assert payload.shape == (4, 2, 10) and payload.dtype == torch.uint8        # 80 bit per frame = 12.8 kbps @ 160 fps
+    assert torch.equal(ad.rx_encoder.unpack(payload), idx)
+    assert torch.equal(ad.rx_encoder.lookup_packed(payload), ad.rx_encoder.lookup(idx))
+
+
+def test_batched_streamer_with_per_stream_reset(gpu, ckpt_root):
+    """4 logical streams, 6 ticks of one 300-sample frame; stream 2 is reset after tick 2 and stream 3
+    misses a frame at tick 4.  Oracle: one batch-1 oracle per stream, driven the same way."""
+    from audiodec_amd.batched_streamer import BatchedAudioDecStreamer
+    n, hop, ticks = 4, 300, 6
+    ad = load_audiodec(ckpt_root, "vctk_v1", 1337, n, 1)
+    st = BatchedAudioDecStreamer(ad, frame_size=hop, max_latency=10.0)
+    audio = np.stack([synth.synth_audio(11, s, ticks * hop) for s in range(n)])
+    oracles = [build_oracle("vctk_v1", 1, 1337) for _ in range(n)]
+    outs, refs = [], []
+    for t in range(ticks):
+        if t == 3:
+            st.reset_stream(2)
+            oracles[2] = build_oracle("vctk_v1", 1, 1337)          # a fresh warmed-up instance
+        frames = []
+        for s in range(n):
+            if s == 3 and t == 4:
+                frames.append(np.zeros(hop, np.float32))             # underrun: the codec sees silence
+                continue
+            st.push(s, audio[s, t * hop:(t + 1) * hop])
+            frames.append(audio[s, t * hop:(t + 1) * hop])
+        outs.append(st.tick())
+        row = []
+        with torch.no_grad():
+            for s in range(n):
+                tx, rx, dec = oracles[s]
+                x = torch.from_numpy(frames[s])[None, None, :]
+                row.append(dec.decode(rx.lookup(tx.quantize(tx.encode(x))))[0, 0].numpy())
+        refs.append(np.stack(row))
+    out, ref = np.stack(outs), np.stack(refs)
+    assert np.abs(out - ref).max() < WAVE_TOL, f"max|dy| = {np.abs(out - ref).max():.3e}"
+    s_ = st.stats()
+    assert s_["underruns"] == 1 and s_["frame_drops"] == 0 and abs(s_["payload_kbps_per_stream"] - 12.8) < 1e-6
