@@ -39,37 +39,86 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
     }
 }
 
-// Cout_total == 1 (output conv 32 -> 1, K7): lanes run along time; each lane walks taps*cin
-// contiguous-per-row inputs with float4 loads, weights come from LDS (broadcast).
+// Cin_total == 1 (encoder input conv 1 -> 32, K7): pure streaming -- 4 B in, 128 B out per step.
+// Cout/4 threads per time step, 4 output channels each: the weights of a thread's 4 channels sit in
+// registers for the whole launch, the 7 input samples are broadcast loads, the store is one coalesced float4.
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_cin1_kernel(ConvArgs a) {
+    const int M = a.cout_g;                                 // groups == 1
+    const int q = M / 4;                                    // float4 pieces per output row; q divides 256
+    const int c4 = threadIdx.x % q;                         // fixed per thread: its 4 channels' weights stay in registers
+    float w[4][TAPS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) w[k][j] = a.w[(size_t)(4 * c4 + k) * TAPS + j];
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + 4 * c4);
+    const int per_block = 256 / q;                          // time steps per workgroup pass
+    for (long long n0 = (long long)blockIdx.x * per_block; n0 < a.n_total; n0 += (long long)gridDim.x * per_block) {
+        const int n = (int)n0 + threadIdx.x / q;
+        if (n >= a.n_total) continue;
+        const int b = n / a.t_out, t = n - b * a.t_out;
+        const float* xin = a.in + (size_t)b * a.in_rows * a.in_ch + a.in_choff;
+        float4 acc = bias;
+        int row = a.in_row0 + t * a.stride;
+        if (row >= a.in_rows) row -= a.in_rows;
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) {
+            const float x = act_apply(xin[(size_t)row * a.in_ch], a.act_in, a.slope);
+            acc.x = fmaf(w[0][j], x, acc.x); acc.y = fmaf(w[1][j], x, acc.y);
+            acc.z = fmaf(w[2][j], x, acc.z); acc.w = fmaf(w[3][j], x, acc.w);
+            row += a.dilation;
+            if (row >= a.in_rows) row -= a.in_rows;
+        }
+        int orow = a.out_cursor + t;
+        if (orow >= a.out_rows) orow -= a.out_rows;
+        *reinterpret_cast<float4*>(a.out + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + 4 * c4) = acc;
+    }
+}
+
+// Cout_total == 1 (output conv 32 -> 1, K7 + tanh): one workgroup = 256 consecutive steps of one stream.
+// The (256 + hist) input rows are staged once into LDS (coalesced float4 loads, activation applied once,
+// row stride Cin+1 so that lanes walking consecutive rows hit distinct banks), then each lane forms its
+// taps*Cin dot product from LDS with the weights broadcast from LDS.
 __global__ __launch_bounds__(256) void conv_cout1_kernel(ConvArgs a) {
-    extern __shared__ float wsh[];
-    for (int i = threadIdx.x; i < a.ktot; i += blockDim.x) wsh[i] = a.w[i];
-    __syncthreads();
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= a.n_total) return;
-    const int b = n / a.t_out, t = n - b * a.t_out;
+    extern __shared__ float sh[];
+    const int C = a.cin_g, ld = C + 1;
+    const int span = (a.taps - 1) * a.dilation;            // == hist for stride 1
+    float* wsh = sh;                                        // [ktot]
+    float* xs = sh + a.ktot;                                // [(256 + span)][C + 1]
+    const int tiles_per_stream = (a.t_out + 255) / 256;
+    const int b = blockIdx.x / tiles_per_stream;
+    const int t0 = (blockIdx.x - b * tiles_per_stream) * 256;
+    const int nt = min(256, a.t_out - t0);
+    for (int i = threadIdx.x; i < a.ktot; i += 256) wsh[i] = a.w[i];
     const float* xin = a.in + (size_t)b * a.in_rows * a.in_ch + a.in_choff;
+    const int rows = nt + span, c4n = C / 4;
+    for (int i = threadIdx.x; i < rows * c4n; i += 256) {
+        const int rr = i / c4n, c4 = i - rr * c4n;
+        int row = a.in_row0 + t0 + rr;
+        row %= a.in_rows;
+        const float4 v = *reinterpret_cast<const float4*>(xin + (size_t)row * a.in_ch + 4 * c4);
+        float* d = xs + rr * ld + 4 * c4;
+        d[0] = act_apply(v.x, a.act_in, a.slope); d[1] = act_apply(v.y, a.act_in, a.slope);
+        d[2] = act_apply(v.z, a.act_in, a.slope); d[3] = act_apply(v.w, a.act_in, a.slope);
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= nt) return;
     float acc = 0.f;
     for (int j = 0; j < a.taps; ++j) {
-        int row = a.in_row0 + t * a.stride + j * a.dilation;
-        row %= a.in_rows;
-        const float4* p = reinterpret_cast<const float4*>(xin + (size_t)row * a.in_ch);
-        const float* wj = wsh + j * a.cin_g;
-        for (int c4 = 0; c4 < a.cin_g / 4; ++c4) {
-            float4 v = p[c4];
-            acc = fmaf(wj[4 * c4 + 0], act_apply(v.x, a.act_in, a.slope), acc);
-            acc = fmaf(wj[4 * c4 + 1], act_apply(v.y, a.act_in, a.slope), acc);
-            acc = fmaf(wj[4 * c4 + 2], act_apply(v.z, a.act_in, a.slope), acc);
-            acc = fmaf(wj[4 * c4 + 3], act_apply(v.w, a.act_in, a.slope), acc);
-        }
+        const float* xr = xs + (t + j * a.dilation) * ld;
+        const float* wj = wsh + j * C;
+        for (int c = 0; c < C; ++c) acc = fmaf(wj[c], xr[c], acc);
     }
     if (a.bias) acc += a.bias[0];
     if (a.res) {
-        int rrow = (a.res_cursor + t) % a.res_rows;
+        int rrow = (a.res_cursor + t0 + t) % a.res_rows;
         acc += a.res[((size_t)b * a.res_rows + rrow) * a.res_ch + a.res_choff];
     }
     acc = act_apply(acc, a.act_out, 0.f);
-    int orow = (a.out_cursor + t) % a.out_rows;
+    int orow = (a.out_cursor + t0 + t) % a.out_rows;
     a.out[((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff] = acc;
 }
 
@@ -78,9 +127,17 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t s) {
     if (a.n_total == 0) return ADK_OK;
     const bool aligned = (a.in_ch % 4 == 0) && (a.in_choff % 4 == 0) && (a.cin_g % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(a.in) & 15) == 0);
-    if (M == 1 && a.up == 1 && aligned && a.ktot * sizeof(float) <= 48 * 1024) {
-        const int blocks = (a.n_total + 255) / 256;
-        hipLaunchKernelGGL(conv_cout1_kernel, dim3(blocks), dim3(256), a.ktot * sizeof(float), s, a);
+    const size_t cout1_lds = ((size_t)a.ktot + (size_t)(256 + (a.taps - 1) * a.dilation) * (a.cin_g + 1)) * sizeof(float);
+    if (M == 1 && a.groups == 1 && a.up == 1 && a.stride == 1 && aligned && cout1_lds <= 64 * 1024) {
+        const int blocks = a.batch * ((a.t_out + 255) / 256);
+        hipLaunchKernelGGL(conv_cout1_kernel, dim3(blocks), dim3(256), cout1_lds, s, a);
+    } else if (a.cin_g == 1 && a.groups == 1 && a.up == 1 && a.taps == 7 && M % 4 == 0 && 256 % (M / 4) == 0 && a.out_ch % 4 == 0 &&
+               a.out_choff % 4 == 0 && !a.res && a.act_out == ADK_ACT_NONE && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+               (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0)) {
+        const int per_block = 256 / (M / 4);
+        long long blocks = ((long long)a.n_total + per_block - 1) / per_block;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_cin1_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else {
         const long long total = (long long)a.n_total * M;
         long long blocks = (total + 255) / 256;

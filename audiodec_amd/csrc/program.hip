@@ -294,7 +294,7 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
         const bool mf = o.impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (o.impl == ADK_IMPL_MFMA || a.groups * a.cout_g >= 32);
-        name = mf ? conv_mfma_cfg_name(conv_mfma_pick(a)) : (a.groups * a.cout_g == 1 ? "conv_cout1" : "conv_direct");
+        name = mf ? conv_mfma_cfg_name(conv_mfma_pick(a)) : (a.groups * a.cout_g == 1 ? "conv_cout1" : (a.cin_g == 1 && a.taps == 7 ? "conv_cin1" : "conv_direct"));
     }
     snprintf(buf, n, "%s", name.c_str());
     return ADK_OK;

@@ -71,7 +71,9 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __
 #pragma unroll
             for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.f;
             const float* Ec = E + c;
-            for (int d0 = 0; d0 < dim; d0 += 16) {        // (2*flatten) @ embed, d ascending   (vq_module.py:95)
+            // (2*flatten) @ embed, d ascending (vq_module.py:95); 16 independent loads in flight per batch
+            // (deeper batches spill at the 1024-thread register budget and run slower)
+            for (int d0 = 0; d0 < dim; d0 += 16) {
                 float e[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) e[u] = (d0 + u < dim) ? Ec[(size_t)(d0 + u) * size] : 0.f;

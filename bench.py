@@ -84,7 +84,7 @@ class TxRxPipeline:
         cur.wait_stream(self.s_tx); cur.wait_stream(self.s_rx)
 
 
-def op_profile(ad, xs, streams, n_steps):
+def op_profile(ad, xs, streams, n_steps, fps=1):
     """Per-op HIP-event durations (events recorded on the launch stream by the C++ runner)."""
     progs = {"encoder": ad.tx_encoder._encoder(), "decoder": ad.decoder._decoder()}
     for p in progs.values():
@@ -103,12 +103,12 @@ def op_profile(ad, xs, streams, n_steps):
             flops = 0.0
             if op.kind == 0:
                 c = op.conv
-                flops = 2.0 * c.groups * c.cout_g * c.taps * c.cin_g * op.rate_out * streams
-            rows.append(dict(prog=k, name=p.op_names[i], kernel=p.describe_op(i, 1), ms=acc[k][i] / n_steps, flops=flops, op=op))
+                flops = 2.0 * c.groups * c.cout_g * c.taps * c.cin_g * op.rate_out * streams * fps
+            rows.append(dict(prog=k, name=p.op_names[i], kernel=p.describe_op(i, fps), ms=acc[k][i] / n_steps, flops=flops, op=op))
     return rows
 
 
-def roofline_from(rows, streams):
+def roofline_from(rows, streams, fps=1):
     by = {}
     for r in rows:
         d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
@@ -125,7 +125,7 @@ def roofline_from(rows, streams):
     roof_ct = None
     if ct:
         r = ct[0]; c = r["op"].conv
-        t_in = r["op"].rate_out
+        t_in = r["op"].rate_out * fps
         cin, cout, s = c.cin_g, c.cout_real, c.up
         bytes_alg = 4.0 * (cin * (t_in + 1) + cout * t_in * s) * streams + 4.0 * cin * cout * 2 * s
         gbs = bytes_alg / (r["ms"] * 1e-3) / 1e9
@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per step (headline: 1)")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no transmitter/receiver overlap)")
     ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently stepped groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -213,12 +214,13 @@ def main():
     synth.write_experiment(tmp.name, dec_tag, rx_steps, SEED, sd=sds[dec_tag])
     NG = args.groups
     assert B % NG == 0
-    ads = [build_audiodec(tmp.name, dev, B // NG, 1) for _ in range(NG)]
+    FPS = args.frames_per_step
+    ads = [build_audiodec(tmp.name, dev, B // NG, FPS) for _ in range(NG)]
     ad = ads[0]
 
     lo, hi = rank * B, (rank + 1) * B            # global stream ids of this rank
     n_buf = 8
-    xs = [torch.from_numpy(np.stack([synth.synth_audio(SEED + j, s, HOP) for s in range(lo, hi)]))[:, None, :].to(dev)
+    xs = [torch.from_numpy(np.stack([synth.synth_audio(SEED + j, s, HOP * FPS) for s in range(lo, hi)]))[:, None, :].to(dev)
           for j in range(n_buf)]
 
     def sync_all():
@@ -260,7 +262,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, dev)
-    frames = world * B * args.steps
+    frames = world * B * args.steps * FPS
     ms_per_step = 1e3 * elapsed / args.steps
     out = {
         "metric": "48 kHz hop-300 frames/s/GPU + per-frame encode+decode latency (ms)",
@@ -270,7 +272,7 @@ def main():
         "config": {"workload": f"{MODEL} full pipeline (symAD encoder+projector -> 8x1024 RVQ -> lookup -> AudioDec-v1 "
                                "HiFi-GAN vocoder), 48 kHz hop 300, streaming, 1 frame per stream per step "
                                "(BASELINE.json config 5 per-GPU share)",
-                   "streams_per_gpu": B, "streams_total": world * B, "frames_per_step_per_stream": 1,
+                   "streams_per_gpu": B, "streams_total": world * B, "frames_per_step_per_stream": FPS,
                    "sample_rate": 48000, "hop": HOP, "weights": "seeded synthetic (audiodec_amd/synth.py), fp32",
                    "schedule": "serial, one HIP stream" if args.serial else
                                "transmitter (encode+RVQ) and receiver (lookup+vocoder) on two HIP streams, codes handed over by event"},
@@ -294,7 +296,7 @@ def main():
     if rank == 0 and world == 1:
         with torch.no_grad():
             if not args.no_op_profile and NG == 1:
-                rows = op_profile(ad, xs, B, 10)
+                rows = op_profile(ad, xs, B, 10, FPS)
                 if args.dump_ops:
                     with open(args.dump_ops, "w") as f:
                         f.write("prog,op,kernel,cin_g,cout_g,groups,taps,dil,t_out_per_stream,us,gflop,tflops\n")
@@ -303,7 +305,7 @@ def main():
                             f.write(f"{r['prog']},{r['name']},{r['kernel']},{c.cin_g},{c.cout_g},{c.groups},{c.taps},{c.dilation},"
                                     f"{r['op'].rate_out},{1e3 * r['ms']:.2f},{r['flops'] / 1e9:.3f},"
                                     f"{(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0:.2f}\n")
-                roof, roof_ct, kernels = roofline_from(rows, B)
+                roof, roof_ct, kernels = roofline_from(rows, B, FPS)
                 out["roofline"] = roof
                 out["roofline_convtr"] = roof_ct
                 out["kernels"] = kernels
@@ -315,7 +317,7 @@ def main():
                 out["pipeline_tflops"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12, 2)
             # single-stream latency: device-complete time of one encode+decode step, B = 1
             ad1 = build_audiodec(tmp.name, dev, 1, 1)
-            x1 = xs[0][:1].contiguous()
+            x1 = xs[0][:1, :, :HOP].contiguous()
             for _ in range(10):
                 step(ad1, x1)
             torch.cuda.synchronize()
@@ -330,6 +332,13 @@ def main():
             out["latency_ms"]["note"] = "one 300-sample frame per stream per call; x on device -> y on device, host-synchronised"
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+    # sticky device-side error flags of the HIP library (0 = clean; see adk_debug_flags in the header)
+    import ctypes
+    from audiodec_amd import native
+    flags = ctypes.c_int32(0)
+    native.check(native.lib().adk_debug_flags(ctypes.byref(flags)), "adk_debug_flags")
+    out["device_error_flags"] = int(flags.value)
+    assert flags.value == 0, f"device error flags {flags.value}: results invalid"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
