@@ -193,12 +193,21 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    # test hook (not used by the driver): ADK_BENCH_BACKEND=gloo ADK_BENCH_ONE_GPU=1 runs all ranks on cuda:0 so the
+    # multi-rank control flow can be exercised on a 1-GPU box; production is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("ADK_BENCH_BACKEND", "nccl")
+    if os.environ.get("ADK_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    coll_dev = dev if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from audiodec_amd import synth, shard, configs
     B = args.streams
@@ -207,7 +216,7 @@ def main():
     sds = {}
     for tag in (enc_tag, dec_tag):
         sd = synth.synth_state_dict(tag, SEED if rank == 0 else SEED + 1)
-        sds[tag] = shard.broadcast_state_dict(sd, src=0, device=dev)
+        sds[tag] = shard.broadcast_state_dict(sd, src=0, device=coll_dev)
     tmp = tempfile.TemporaryDirectory()
     sr, _, tx_steps, _, rx_steps = configs.alias(MODEL)
     synth.write_experiment(tmp.name, enc_tag, tx_steps, SEED, sd=sds[enc_tag])
@@ -261,7 +270,7 @@ def main():
             pipe.exit()
         sync_all()
         elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, dev)
+    elapsed = shard.max_over_ranks(elapsed, coll_dev)
     frames = world * B * args.steps * FPS
     ms_per_step = 1e3 * elapsed / args.steps
     out = {
