@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <algorithm>
 #include "../../include/audiodec_hip.h"
 
 namespace adk {
@@ -49,6 +50,9 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 struct Workspace { float* ptr = nullptr; size_t bytes = 0; size_t flags_offset = 0; unsigned epoch = 0; };
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s, Workspace& ws);   // needs wfrag, cin_g % 32 == 0
 size_t conv_mfma_workspace_bytes(size_t* flags_offset);
+bool conv_rl_supported(const ConvArgs& a);          // rows-in-LDS kernel (stride 1, 32/64 channels per group, time-rich)
+bool conv_rl_preferred(const ConvArgs& a);          // AUTO heuristic: enough (stream, group, tile) workgroups to fill the chip
+int launch_conv_rl(const ConvArgs& a, hipStream_t s);
 int* flags_word();                                   // device address of the sticky debug/error flags
 int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 bool conv_mfma_supported(const ConvArgs& a);

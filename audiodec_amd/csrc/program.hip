@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 
 namespace adk {
 
@@ -69,12 +70,20 @@ static int ensure_workspace(Workspace& w) {
     return ADK_OK;
 }
 
+static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
+
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
+    if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
     const bool ok = conv_mfma_supported(a);
+    if (impl == ADK_IMPL_MFMA_ROWS) {
+        if (!conv_rl_supported(a)) return fail(ADK_ERR_SHAPE, "conv: rows-in-LDS kernel needs stride 1, 32/64 channels per group, w_frag");
+        return launch_conv_rl(a, s);
+    }
     const bool want_mfma = (impl == ADK_IMPL_MFMA) || (impl == ADK_IMPL_AUTO && ok && a.groups * a.cout_g >= 32);
     if (impl == ADK_IMPL_MFMA && !ok)
         return fail(ADK_ERR_SHAPE, "conv: MFMA kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
     if (want_mfma) {
+        if (impl == ADK_IMPL_AUTO && g_use_rl && conv_rl_preferred(a)) return launch_conv_rl(a, s);
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
         return launch_conv_mfma(a, s, ws);
@@ -294,7 +303,10 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
         const bool mf = o.impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (o.impl == ADK_IMPL_MFMA || a.groups * a.cout_g >= 32);
-        name = mf ? conv_mfma_cfg_name(conv_mfma_pick(a)) : (a.groups * a.cout_g == 1 ? "conv_cout1" : (a.cin_g == 1 && a.taps == 7 ? "conv_cin1" : "conv_direct"));
+        if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
+        const bool rl = mf && ((o.impl == ADK_IMPL_MFMA_ROWS && conv_rl_supported(a)) || (o.impl == ADK_IMPL_AUTO && g_use_rl && conv_rl_preferred(a)));
+        if (rl) name = a.cin_g == 32 ? "conv_rl<32>" : "conv_rl<64>";
+        else name = mf ? conv_mfma_cfg_name(conv_mfma_pick(a)) : (a.groups * a.cout_g == 1 ? "conv_cout1" : (a.cin_g == 1 && a.taps == 7 ? "conv_cin1" : "conv_direct"));
     }
     snprintf(buf, n, "%s", name.c_str());
     return ADK_OK;

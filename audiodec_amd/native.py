@@ -13,7 +13,7 @@ ABI_VERSION = 3
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA = 0, 1, 2
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS = 0, 1, 2, 3
 OP_CONV, OP_RING_WRITE, OP_MEAN = 0, 1, 2
 
 

@@ -40,7 +40,7 @@ enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_E
 enum { ADK_ACT_NONE = 0, ADK_ACT_ELU = 1, ADK_ACT_LEAKY = 2, ADK_ACT_TANH = 3 };
 
 /* kernel selection for adk_causal_conv (ADK_IMPL_AUTO in production; others for tests/benchmarks) */
-enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 };
+enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K implicit GEMM */, ADK_IMPL_MFMA_ROWS = 3 /* rows-in-LDS */ };
 
 const char* adk_last_error(void);
 int adk_abi_version(void);

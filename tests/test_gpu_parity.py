@@ -112,8 +112,9 @@ def test_residual_vq_matches_reference_layers(gpu, golden_dir):
 # fused activation / grouped / residual paths against the oracle on random tensors
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,k,s,d,gr,act,B,L", [
-    (64, 64, 7, 1, 3, 1, "ELU", 3, 50), (96, 96, 11, 1, 5, 3, "LeakyReLU", 5, 20), (128, 256, 10, 5, 1, 1, None, 7, 25),
-    (512, 64, 3, 1, 1, 1, "ELU", 33, 1), (32, 96, 3, 1, 1, 1, "LeakyReLU", 2, 301)])
+    (64, 64, 7, 1, 3, 1, "ELU", 3, 50), (96, 96, 11, 1, 5, 3, "LeakyReLU", 5, 40), (128, 256, 10, 5, 1, 1, None, 7, 25),
+    (512, 64, 3, 1, 1, 1, "ELU", 33, 1), (32, 96, 3, 1, 1, 1, "LeakyReLU", 2, 301), (192, 192, 11, 1, 5, 3, "LeakyReLU", 2, 500),
+    (32, 32, 7, 1, 9, 1, "ELU", 4, 333)])
 def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
     from audiodec_amd import layers, native
     g = torch.Generator().manual_seed(cin * 7 + k)
@@ -122,7 +123,10 @@ def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
     fn = {None: lambda v: v, "ELU": torch.nn.ELU(), "LeakyReLU": torch.nn.LeakyReLU(0.1)}[act]
     pad = torch.zeros(B, cin, (k - 1) * d)
     mods = []
-    for impl in (native.IMPL_DIRECT, native.IMPL_MFMA):
+    impls = [native.IMPL_DIRECT, native.IMPL_MFMA]
+    if s == 1 and cin // gr in (32, 64) and (cout // gr) % 32 == 0 and L >= 24:
+        impls.append(native.IMPL_MFMA_ROWS)              # the rows-in-LDS kernel takes this shape
+    for impl in impls:
         m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
         m.set_activation(act, 0.1)
         m.impl = impl

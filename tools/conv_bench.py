@@ -76,8 +76,9 @@ if __name__ == "__main__":
     ap.add_argument("--cfg", default="-1")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--impl", type=int, default=native.IMPL_MFMA, help="2 stream-K, 3 rows-in-LDS, 0 auto")
     a = ap.parse_args()
     for sh in a.shape.split(","):
         for cfg in a.cfg.split(","):
-            us, tf = run(sh, int(cfg), a.batch, a.iters)
-            print(f"{sh:5s} cfg {cfg:>2s}  B={a.batch}  {us:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+            us, tf = run(sh, int(cfg), a.batch, a.iters, a.impl)
+            print(f"{sh:5s} impl {a.impl} cfg {cfg:>2s}  B={a.batch}  {us:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
