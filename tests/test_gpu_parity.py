@@ -28,6 +28,8 @@ def _load(golden_dir, name):
 @pytest.fixture(scope="module")
 def gpu():
     assert torch.cuda.is_available(), "these tests need a HIP device"
+    import __graft_entry__
+    __graft_entry__.build()                  # no-op when the in-tree .so is newer than its sources
     from audiodec_amd import native
     native.lib()
     return DEV
