@@ -44,6 +44,7 @@ struct RingMeanArgs {
     int n, channels, batch, t;
 };
 int launch_ring_mean(const RingMeanArgs& m, hipStream_t s);
+int launch_hist_replicate(float* ring, int rows, int channels, int cursor, int hist, int batch, hipStream_t s);
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 // scratch of the stream-K conv: partial accumulators of cut tiles + publish flags (zeroed once at
 // allocation; flags carry a per-launch epoch, so they are never reset)

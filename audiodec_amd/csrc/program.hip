@@ -133,6 +133,7 @@ struct adk_program {
     float* arena = nullptr; int64_t arena_floats = 0;
     Workspace ws;
     bool profiling = false;
+    bool fresh = true;              // no step since create / reset (ADK_OP_HIST_REPLICATE runs only then)
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
     std::vector<float> last_ms;
 };
@@ -194,6 +195,9 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
                 if (rings[o.mean_rings[k]].channels != rings[o.out_ring].channels || rings[o.mean_rings[k]].rate != rings[o.out_ring].rate)
                     return bail(ADK_ERR_SHAPE, "program_create: mean sources must match the output ring");
             }
+        } else if (o.kind == ADK_OP_HIST_REPLICATE) {
+            if (!ring_ok(o.in_ring) || rings[o.in_ring].external >= 0)
+                return bail(ADK_ERR_ARG, "program_create: hist_replicate needs an arena ring");
         } else {
             return bail(ADK_ERR_ARG, "program_create: unknown op kind");
         }
@@ -267,6 +271,12 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
             }
             int rc = launch_ring_mean(m, s);
             if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+        } else if (o.kind == ADK_OP_HIST_REPLICATE) {
+            if (p->fresh) {
+                adk_ring_view v = view_of(p, o.in_ring, frames, ext, 0);
+                int rc = launch_hist_replicate(v.base, v.rows, v.channels, v.cursor, p->rings[o.in_ring].hist, p->batch, s);
+                if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+            }
         } else {
             adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
             const float* mean = o.mean_off >= 0 ? p->weights + o.mean_off : nullptr;
@@ -280,13 +290,14 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
     for (size_t i = 0; i < p->rings.size(); ++i)
         if (p->rings[i].external < 0)
             p->cursor[i] = (int32_t)(((long long)p->cursor[i] + (long long)frames * p->rings[i].rate) % p->rows[i]);
+    p->fresh = false;
     return ADK_OK;
 }
 
 extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frames, char* buf, int32_t n) {
     if (!p || !buf || n <= 0 || op < 0 || op >= (int)p->ops.size()) return fail(ADK_ERR_ARG, "program_describe_op: bad arguments");
     const adk_op_desc& o = p->ops[op];
-    std::string name = o.kind == ADK_OP_MEAN ? "ring_mean" : "ring_write";
+    std::string name = o.kind == ADK_OP_MEAN ? "ring_mean" : (o.kind == ADK_OP_HIST_REPLICATE ? "hist_replicate" : "ring_write");
     if (o.kind == ADK_OP_CONV) {
         adk_conv_desc d = o.conv;
         d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
@@ -321,6 +332,7 @@ extern "C" int adk_program_reset(adk_program* p, void* stream) {
                                      static_cast<hipStream_t>(stream)));
         p->cursor[i] = 0;
     }
+    p->fresh = true;
     return ADK_OK;
 }
 

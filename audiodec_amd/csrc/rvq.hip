@@ -189,6 +189,29 @@ int launch_ring_mean(const RingMeanArgs& m, hipStream_t s) {
     return ADK_OK;
 }
 
+// ring[b][cursor - h][c] = ring[b][cursor][c] for h = 1..hist  (ReplicationPad1d((hist, 0)), conv_layer.py:190)
+__global__ __launch_bounds__(256) void hist_replicate_kernel(float* __restrict__ ring, int rows, int channels, int cursor, int hist, int batch) {
+    const long long total = (long long)batch * hist * channels;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(gid % channels);
+        const long long bh = gid / channels;
+        const int h = (int)(bh % hist) + 1, b = (int)(bh / hist);
+        int row = cursor - h;
+        if (row < 0) row += rows;
+        ring[((size_t)b * rows + row) * channels + c] = ring[((size_t)b * rows + cursor) * channels + c];
+    }
+}
+
+int launch_hist_replicate(float* ring, int rows, int channels, int cursor, int hist, int batch, hipStream_t s) {
+    const long long total = (long long)batch * hist * channels;
+    if (total == 0) return ADK_OK;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(hist_replicate_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ring, rows, channels, cursor, hist, batch);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
 }  // namespace adk
 
 using namespace adk;

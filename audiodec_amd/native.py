@@ -9,12 +9,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaudiodec_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS = 0, 1, 2, 3
-OP_CONV, OP_RING_WRITE, OP_MEAN = 0, 1, 2
+OP_CONV, OP_RING_WRITE, OP_MEAN, OP_HIST_REPLICATE = 0, 1, 2, 3
 
 
 class RingView(C.Structure):

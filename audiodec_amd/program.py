@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import arch, native
-from .native import (ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_TANH, IMPL_AUTO, OP_CONV, OP_MEAN, OP_RING_WRITE,
+from .native import (ACT_ELU, ACT_LEAKY, ACT_NONE, ACT_TANH, IMPL_AUTO, OP_CONV, OP_HIST_REPLICATE, OP_MEAN, OP_RING_WRITE,
                      ConvDesc, OpDesc, RingDesc)
 
 
@@ -101,8 +101,9 @@ class Blob:
 # program builder
 # ---------------------------------------------------------------------------------------------
 class Builder:
-    def __init__(self, sd, specs):
+    def __init__(self, sd, specs, offline=False):
         self.sd = sd
+        self.offline = offline          # lower Generator.forward (file-level drivers) instead of the streaming inference
         self.specs = arch.by_name(specs)
         self.blob = Blob()
         self.rings, self.ops, self.op_names = [], [], []
@@ -150,6 +151,18 @@ class Builder:
         self.ops.append(op)
         self.op_names.append("mean")
 
+    def hist_replicate(self, ring):
+        """First step after a reset: history rows of `ring` <- its first new row (the ReplicationPad1d of
+        CausalConvTranspose1d.forward, layers/conv_layer.py:189-192)."""
+        op = OpDesc()
+        op.kind = OP_HIST_REPLICATE
+        op.in_ring, op.out_ring, op.res_ring = ring, -1, -1
+        op.w_off, op.wf_off, op.b_off, op.mean_off, op.scale_off = -1, -1, -1, -1, -1
+        op.ext_src = -1
+        op.rate_out = self.rings[ring]["rate"]
+        self.ops.append(op)
+        self.op_names.append("hist_replicate")
+
     def conv(self, name, in_ring, out_ring, act_in=ACT_NONE, slope=0.0, act_out=ACT_NONE, res_ring=-1,
              in_group_stride=None, res_group_stride=None, impl=IMPL_AUTO):
         s = self.specs[name]
@@ -177,6 +190,8 @@ class Builder:
         d.res_group_stride = d.cout_g if res_group_stride is None else res_group_stride
         d.act_in, d.act_in_slope, d.act_out = act_in, slope, act_out
         self.need_hist(in_ring, d.hist)
+        if s.kind == "convT" and self.offline:
+            self.hist_replicate(in_ring)
         op = OpDesc()
         op.kind = OP_CONV
         op.in_ring, op.out_ring, op.res_ring = in_ring, out_ring, res_ring
@@ -248,10 +263,11 @@ def build_encoder(sd, p):
     return b
 
 
-def build_sym_decoder(sd, p):
-    """Decoder.decode / ActivateDecoder.decode (decoder.py:142-148, 203-214).  ext: [zq, y]."""
+def build_sym_decoder(sd, p, offline=False):
+    """Decoder.decode / ActivateDecoder.decode (decoder.py:142-148, 203-214), or with offline=True
+    Decoder.forward (:136-140: same layers, replication pad in front of the transposed convs).  ext: [zq, y]."""
     specs = arch.autoencoder_decoder_convs(p)
-    b = Builder(sd, specs)
+    b = Builder(sd, specs, offline)
     act, slope = _act_of(p)
     activate = p.get("codec", "audiodec") == "activate_audiodec"
     ch, ratios, strides = p.get("decode_channels", 32), p.get("dec_ratios", (16, 8, 4, 2)), p.get("dec_strides", (5, 5, 4, 3))
@@ -273,10 +289,11 @@ def build_sym_decoder(sd, p):
     return b
 
 
-def build_hifigan(sd, p):
-    """HiFiGAN StreamGenerator.decode (HiFiGAN.py:268-296).  ext: [zq, y]."""
+def build_hifigan(sd, p, offline=False):
+    """HiFiGAN StreamGenerator.decode (HiFiGAN.py:268-296), or with offline=True Generator.forward
+    (:141-161).  ext: [zq, y]."""
     specs = arch.hifigan_convs(p)
-    b = Builder(sd, specs)
+    b = Builder(sd, specs, offline)
     act, slope = _act_of(p, "LeakyReLU")
     multigroup = arch.hifigan_is_multigroup(p)
     groups = p.get("groups", 1)

@@ -51,6 +51,7 @@ class _StreamBase:
         self._device = None
         self.num_streams = 1
         self.max_frames = 16
+        self.offline = False
         self._warm = {}
 
     # ---- torch.nn.Module surface the reference's loader touches (bin/stream.py:59-61) ----
@@ -71,6 +72,17 @@ class _StreamBase:
             raise ValueError("num_streams and max_frames must be >= 1")
         if (num_streams, max_frames) != (self.num_streams, self.max_frames):
             self.num_streams, self.max_frames = int(num_streams), int(max_frames)
+            self._drop_programs()
+        return self
+
+    def set_offline(self, offline=True):
+        """offline=True lowers the NON-streaming Generator.forward used by the file-level drivers
+        (codecTest.py:78-95, codecStatistic.py:92-97): every utterance starts from reset_buffer() and the
+        transposed convs see the replication pad of CausalConvTranspose1d.forward (conv_layer.py:189-192)
+        instead of a zero pad_buffer.  Everything else (zero left-pad of CausalConv1d.forward) already
+        equals streaming from the reset state."""
+        if bool(offline) != self.offline:
+            self.offline = bool(offline)
             self._drop_programs()
         return self
 
@@ -203,7 +215,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
 
     def _decoder(self):
         if self._dec is None:
-            self._dec = program.HipProgram(program.build_sym_decoder(self._sd, self.params), self.num_streams,
+            self._dec = program.HipProgram(program.build_sym_decoder(self._sd, self.params, self.offline), self.num_streams,
                                            self.max_frames, self._dev())
         return self._dec
 
@@ -275,6 +287,21 @@ class AutoEncoderStreamGenerator(_StreamBase):
             "adk_rvq_encode")
         idx = idx.reshape(self.n_q, B, T)
         return idx.squeeze(1) if B == 1 else idx
+
+    def quantizer_forward(self, z):
+        """Quantizer.forward in eval mode (quantizer.py:32-35 -> ResidualVQ.forward, vq_module.py:119-134):
+        z (B, code_dim, T) -> zq (B, code_dim, T), the sum of the straight-through stage outputs."""
+        dev = self._dev()
+        embed, enorm = self._quantizer()
+        B, D, T = z.shape
+        zt = z.to(device=dev, dtype=torch.float32).transpose(2, 1).contiguous()
+        idx = torch.empty(self.n_q, B * T, dtype=torch.int64, device=dev)
+        zq = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        native.check(native.lib().adk_rvq_encode(
+            C.c_void_p(zt.data_ptr()), C.c_void_p(embed.data_ptr()), C.c_void_p(enorm.data_ptr()),
+            C.c_void_p(idx.data_ptr()), C.c_void_p(zq.data_ptr()), B * T, self.n_q, self.dim, self.size,
+            native.current_stream(dev)), "adk_rvq_encode")
+        return zq.transpose(2, 1)
 
     def lookup(self, idx):
         """idx (n_q, T) -> zq (1, T, code_dim); (n_q, B, T) -> (B, T, code_dim)  (AudioDec.py:242-243)."""
@@ -364,7 +391,7 @@ class HiFiGANStreamGenerator(_StreamBase):
 
     def _decoder(self):
         if self._dec is None:
-            self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params), self.num_streams,
+            self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline), self.num_streams,
                                            self.max_frames, self._dev())
         return self._dec
 

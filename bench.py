@@ -170,6 +170,30 @@ def cpu_baseline(budget_s=12.0, threads=4):
             "ms_per_frame": round(1e3 * dt / n, 2)}
 
 
+def cpu_cfg1(threads=4, reps=3):
+    """BASELINE config 1 on the host cores: demoFile.py:58-61 (one 24000-sample libritts_sym file, one-shot
+    encode -> quantize -> lookup -> decode) through the CPU port."""
+    from audiodec_amd import synth, configs
+    from oracle import audiodec_oracle as O
+    torch.set_num_threads(threads)
+    _, enc_tag, _, dec_tag, _ = configs.alias("libritts_sym")
+    _, _, pe = configs.experiment(enc_tag)
+    mt_d, _, pd = configs.experiment(dec_tag)
+    tx = O.AutoEncoderOracle(synth.synth_state_dict(enc_tag, SEED), pe, 1)
+    zq0 = tx.initial_encoder(8192)
+    dec = O.build_decoder_oracle(synth.synth_state_dict(dec_tag, SEED), mt_d, pd, 1)
+    dec.initial_decoder(zq0)
+    x = torch.from_numpy(synth.synth_audio(SEED, 0, 24000))[None, None, :]
+    best = 1e9
+    with torch.no_grad():
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            dec.decode(tx.lookup(tx.quantize(tx.encode(x))))
+            best = min(best, time.perf_counter() - t0)
+    return {"ms": round(1e3 * best, 1), "frames_per_s": round(80 / best, 1), "cores": threads,
+            "what": "libritts_sym 24000-sample file, one-shot round trip, CPU port, best of %d" % reps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +204,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no transmitter/receiver overlap)")
     ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently stepped groups")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cfg1", action="store_true", help="also time BASELINE config 1 (file round trip) on the host CPU")
     ap.add_argument("--no-op-profile", action="store_true")
     ap.add_argument("--dump-ops", type=str, default=None, help="write the per-op HIP-event table (CSV) here")
     args = ap.parse_args()
@@ -341,6 +366,8 @@ def main():
             out["latency_ms"]["note"] = "one 300-sample frame per stream per call; x on device -> y on device, host-synchronised"
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if args.cpu_cfg1:
+                out["cpu_baseline"]["config1_file_roundtrip"] = cpu_cfg1()
     # sticky device-side error flags of the HIP library (0 = clean; see adk_debug_flags in the header)
     import ctypes
     from audiodec_amd import native

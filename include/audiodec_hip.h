@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 3
+#define ADK_ABI_VERSION 4
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -167,7 +167,12 @@ typedef struct {
     int64_t arena_off;   /* float offset of this ring in the arena (batch * rows * channels floats)  */
 } adk_ring_desc;
 
-enum { ADK_OP_CONV = 0, ADK_OP_RING_WRITE = 1, ADK_OP_MEAN = 2 };
+enum { ADK_OP_CONV = 0, ADK_OP_RING_WRITE = 1, ADK_OP_MEAN = 2,
+       /* First step after create/reset only: copy the first new row of ring `in_ring` into its history rows.
+          This is the replication left-pad of the NON-streaming CausalConvTranspose1d.forward
+          (layers/conv_layer.py:189-192) that the offline drivers (codecTest.py / codecStatistic.py) run;
+          streaming inference starts from a zero pad_buffer instead and never uses this op. */
+       ADK_OP_HIST_REPLICATE = 3 };
 
 typedef struct {
     int32_t kind;                        /* ADK_OP_*                                                  */

@@ -290,6 +290,18 @@ class AutoEncoderOracle(_Streaming):
         zq = self.lookup(idx)
         return z, idx, zq, self.decode(zq, streaming=False)
 
+    def analyze(self, x):
+        """What codecTest.py:78-88 / codecStatistic.py:92-97 run: ``encoder`` -> ``projector`` -> ``quantizer``
+        forwards (eval mode); x (B, 1, L) -> zq (B, 64, T').  Quantizer.forward (quantizer.py:32-35) ->
+        ResidualVQ.forward (vq_module.py:119-134) does the same value arithmetic as forward_index."""
+        z = self.encode(x, streaming=False)
+        zq = torch.cat([rvq_forward_index(z[b:b + 1].transpose(2, 1), self.embeds)[0] for b in range(z.shape[0])], 0)
+        return zq.transpose(2, 1)
+
+    def synthesize(self, zq):
+        """codecTest.py:90-95 for a symAudioDec decoder: ``decoder.decoder(zq)`` (Decoder.forward)."""
+        return self._decoder(zq, streaming=False)
+
 
 # ----------------------------------------------------------------------------------------------
 # models/vocoder/HiFiGAN.py (+ modules/residual_block.py, modules/multi_fusion.py)
@@ -346,6 +358,10 @@ class HiFiGANOracle(_Streaming):
 
     def initial_decoder(self, c):
         self.decode(c.expand(self.batch, -1, -1) if c.shape[0] != self.batch else c)      # :264-265
+
+    def synthesize(self, zq):
+        """codecTest.py:90-95 for a vocoder decoder: Generator.forward (HiFiGAN.py:141-161); zq (B, 64, T')."""
+        return self.decode(zq.transpose(2, 1), streaming=False)
 
 
 def build_decoder_oracle(sd, model_type, generator_params, batch=1):

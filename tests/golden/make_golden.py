@@ -187,6 +187,55 @@ def op_cases(ref_audiodec):
     print("ops:", len(out), "arrays ->", os.path.getsize(path), "B (oracle == reference: exact)")
 
 
+def offline_case(name, model, lengths):
+    """Known answers for the file-level drivers (codecTest.py:78-95, codecStatistic.py:92-113): the reference's
+    NON-streaming Generator classes run ``encoder -> projector -> quantizer`` and ``decoder`` / the vocoder
+    forward on whole (ragged-length) utterances; StandardScaler over the code vectors gives the stats."""
+    from models.autoencoder.AudioDec import Generator as ref_audiodec_generator
+    from models.vocoder.HiFiGAN import Generator as ref_hifigan_generator
+    from sklearn.preprocessing import StandardScaler
+    torch.set_num_threads(4)
+    sr, enc_tag, _, dec_tag, _ = configs.alias(model)
+    _, _, pe = configs.experiment(enc_tag)
+    mt_d, _, pd = configs.experiment(dec_tag)
+    sd_e, sd_d = synth.synth_state_dict(enc_tag, SEED), synth.synth_state_dict(dec_tag, SEED)
+    enc = ref_audiodec_generator(**pe)
+    enc.load_state_dict(sd_e)
+    enc.eval()
+    if mt_d in ("HiFiGAN", "UnivNet"):
+        dec = ref_hifigan_generator(**pd)
+    else:
+        dec = ref_audiodec_generator(**pd)
+    dec.load_state_dict(sd_d)
+    dec.eval()
+    o_enc = O.AutoEncoderOracle(sd_e, pe, 1)
+    o_dec = O.build_decoder_oracle(sd_d, mt_d, pd, 1)
+    out = dict(model=model, seed=SEED, lengths=np.asarray(lengths, np.int64), sample_rate=sr)
+    scaler = StandardScaler()
+    with torch.no_grad():
+        for n, L in enumerate(lengths):
+            audio = synth.synth_audio(SEED, 100 + n, L)[:, None].astype(np.float64)       # (T, C=1) like sf.read
+            x = torch.tensor(audio, dtype=torch.float).transpose(1, 0).unsqueeze(1)        # codecTest.py:80-83
+            zq, _, _ = enc.quantizer(enc.projector(enc.encoder(x)))
+            y = dec(zq) if mt_d in ("HiFiGAN", "UnivNet") else dec.decoder(zq)
+            ozq = o_enc.analyze(x)
+            oy = o_dec.synthesize(ozq)
+            assert torch.equal(ozq, zq), f"{name}: oracle zq differs from the reference forward"
+            assert torch.equal(oy, y), f"{name}: oracle y differs by {float((oy - y).abs().max())}"
+            scaler.partial_fit(zq.squeeze(0).transpose(1, 0).numpy())
+            out[f"zq{n}"], out[f"y{n}"] = zq.numpy(), y.numpy()
+    out["stats"] = np.stack([scaler.mean_, scaler.scale_], axis=0).astype(np.float32)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(lengths)} utterances, |y|max {max(float(np.abs(out[f'y{n}']).max()) for n in range(len(lengths))):.3f} "
+          f"-> {os.path.getsize(path)} B  (oracle == reference: exact)")
+
+
+OFFLINE = {
+    "vctk_v1_offline": ("vctk_v1", [2000, 1234]),
+    "vctk_sym_offline": ("vctk_sym", [1500, 901]),
+}
+
 CASES = {
     # name: (model alias, n_streams, chunk schedule in frames, one-shot length in samples)
     "vctk_sym_stream": ("vctk_sym", 2, [1, 2, 1, 3], None),
@@ -200,7 +249,7 @@ CASES = {
 
 
 def main(argv):
-    names = argv[1:] or (["ops"] + list(CASES))
+    names = argv[1:] or (["ops"] + list(CASES) + list(OFFLINE))
     ref_audiodec = import_reference()
     with tempfile.TemporaryDirectory() as root:
         os.chdir(root)
@@ -208,6 +257,13 @@ def main(argv):
         for name in names:
             if name == "ops":
                 op_cases(ref_audiodec)
+                continue
+            if name in OFFLINE:
+                model, lengths = OFFLINE[name]
+                if model not in written:
+                    synth.write_model(root, model, SEED)       # the vocoder Generator reads stats/*.npy (HiFiGAN.py:126-131)
+                    written.add(model)
+                offline_case(name, model, lengths)
                 continue
             model, n, sched, one = CASES[name]
             if model not in written:

@@ -1,0 +1,227 @@
+"""File-level evaluation drivers (audiodec_amd/offline.py; reference codecTest.py / codecStatistic.py).
+
+CPU: the oracle's non-streaming forward against the reference fixtures (tests/golden/*_offline.npz, made by
+running the reference's Generator classes), WAV / dataset plumbing, the StandardScaler restatement.
+GPU: TestMain / StatisticMain on the HIP path against the same fixtures and, end to end over WAV files,
+against the oracle.
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from audiodec_amd import configs, synth
+from oracle import audiodec_oracle as O
+
+TOL = 2e-5
+WAVE_TOL = 1e-4
+OFFLINE = ["vctk_v1_offline", "vctk_sym_offline"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=False)
+
+
+def _audio(seed, n, L):
+    return synth.synth_audio(seed, 100 + n, L)[:, None].astype(np.float64)        # (T, 1) like sf.read(always_2d=True)
+
+
+def _oracles(model, seed):
+    _, enc_tag, _, dec_tag, _ = configs.alias(model)
+    _, _, pe = configs.experiment(enc_tag)
+    mt_d, _, pd = configs.experiment(dec_tag)
+    enc = O.AutoEncoderOracle(synth.synth_state_dict(enc_tag, seed), pe, 1)
+    dec = O.build_decoder_oracle(synth.synth_state_dict(dec_tag, seed), mt_d, pd, 1)
+    return enc, dec
+
+
+@pytest.mark.parametrize("name", OFFLINE)
+def test_oracle_forward_matches_reference_fixture(golden_dir, name):
+    torch.set_num_threads(4)
+    g = _load(golden_dir, name)
+    enc, dec = _oracles(str(g["model"]), int(g["seed"]))
+    hop = 300
+    for n, L in enumerate(g["lengths"]):
+        x = torch.tensor(_audio(int(g["seed"]), n, int(L)), dtype=torch.float).transpose(1, 0).unsqueeze(1)
+        with torch.no_grad():
+            zq = enc.analyze(x)
+            y = dec.synthesize(zq)
+        frames = -(-int(L) // hop)                              # ragged lengths: ceil at every strided conv
+        assert zq.shape == (1, 64, frames) and y.shape == (1, 1, frames * hop)
+        assert float((zq - torch.from_numpy(g[f"zq{n}"])).abs().max()) <= TOL
+        assert float((y - torch.from_numpy(g[f"y{n}"])).abs().max()) <= TOL
+
+
+def test_forward_differs_from_streaming_from_reset_by_the_replication_pad(golden_dir):
+    """Why ADK_OP_HIST_REPLICATE exists: from the reset state, streaming inference and the non-streaming
+    forward agree on the encoder side (zero left-pad == zero pad_buffer) but not behind the transposed
+    convs, whose forward pads by replication (conv_layer.py:189-192)."""
+    g = _load(golden_dir, "vctk_sym_offline")
+    seed = int(g["seed"])
+    enc, dec = _oracles("vctk_sym", seed)
+    x = torch.tensor(_audio(seed, 0, 1500), dtype=torch.float).transpose(1, 0).unsqueeze(1)
+    zq = torch.from_numpy(g["zq0"])
+    with torch.no_grad():
+        z_fwd = enc.encode(x, streaming=False)
+        enc.reset_buffer()
+        z_str = enc.encode(x, streaming=True)
+        y_fwd = dec.synthesize(zq)
+        dec.reset_buffer()
+        y_str = dec.decode(zq.transpose(2, 1), streaming=True)
+    assert torch.equal(z_fwd, z_str)
+    assert float((y_fwd - y_str).abs().max()) > 1e-3
+
+
+def test_wav_io_and_dataset(tmp_path):
+    from audiodec_amd import offline
+    x = np.clip(0.3 * np.random.default_rng(0).standard_normal((1000, 2)), -1, 1)
+    p = str(tmp_path / "b_utt.wav")
+    offline.write_wav_pcm16(p, x, 48000)
+    offline.write_wav_pcm16(str(tmp_path / "a_utt.wav"), x[:, :1], 48000)
+    r = offline.read_wav(p)
+    assert r.shape == (1000, 2) and r.dtype == np.float64
+    assert np.abs(r - x).max() <= 2.0 / 32767        # rounding + the 32767 / 32768 scale asymmetry of PCM_16
+    ds = offline.SingleDataset(str(tmp_path), return_utt_id=True)
+    assert [u for u, _ in ds] == ["a_utt", "b_utt"] and ds[0][1].shape == (1000, 1)       # sorted, always 2-D
+    assert len(offline.SingleDataset(str(tmp_path), subset_num=1)) == 1
+    with pytest.raises(ValueError):
+        offline.SingleDataset(str(tmp_path / "missing"))
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(AssertionError):
+        offline.SingleDataset(str(tmp_path / "empty"))
+
+
+def test_partial_fit_restates_standard_scaler():
+    from sklearn.preprocessing import StandardScaler
+    from audiodec_amd import offline
+    rng = np.random.default_rng(1)
+    chunks = [rng.standard_normal((n, 64)).astype(np.float32) * 3 + 1 for n in (7, 5, 19)]
+    sc, st = StandardScaler(), None
+    for c in chunks:
+        sc.partial_fit(c)
+        st = offline._partial_fit(st, c)
+    assert np.allclose(st[0], sc.mean_, rtol=0, atol=1e-12) and np.allclose(np.sqrt(st[1]), sc.scale_, rtol=0, atol=1e-12)
+
+
+def test_drivers_fail_loudly_without_a_gpu(tmp_path):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from audiodec_amd import native, offline
+    root = str(tmp_path)
+    _, enc, dec = synth.write_model(root, "vctk_sym", 1337)
+    args = types.SimpleNamespace(encoder=enc, decoder=dec)
+    with pytest.raises(native.NativeError):
+        offline.TestMain(args)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU
+# ------------------------------------------------------------------------------------------------
+def _write_data_section(ckpt, data_root):
+    import yaml
+    cfg_path = os.path.join(os.path.dirname(ckpt), "config.yml")
+    with open(cfg_path) as f:
+        cfg = yaml.safe_load(f)
+    cfg["data"] = {"path": data_root, "subset": {"train": "train", "clean_test": "test"}}
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(cfg, f)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    import __graft_entry__
+    __graft_entry__.build()
+    from audiodec_amd import native
+    native.lib()
+    return "cuda:0"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", OFFLINE)
+def test_testmain_matches_reference_forward(gpu, golden_dir, tmp_path, name):
+    from audiodec_amd import offline
+    g = _load(golden_dir, name)
+    model, seed = str(g["model"]), int(g["seed"])
+    root = str(tmp_path)
+    _, enc, dec = synth.write_model(root, model, seed)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        tm = offline.TestMain(types.SimpleNamespace(encoder=enc, decoder=dec), max_frames=3)   # 3-hop chunks: 7 frames = 3 steps
+        tm.load_encoder()
+        tm.load_decoder()
+    finally:
+        os.chdir(cwd)
+    for rep in range(2):                                         # second pass: per-utterance reset really resets
+        for n, L in enumerate(g["lengths"]):
+            zq = tm.encode(_audio(seed, n, int(L)))
+            y = tm.decode(zq)
+            dz = float((zq.cpu() - torch.from_numpy(g[f"zq{n}"])).abs().max())
+            dy = float((y.cpu() - torch.from_numpy(g[f"y{n}"])).abs().max())
+            assert zq.shape == g[f"zq{n}"].shape and y.shape == g[f"y{n}"].shape
+            assert dz <= 1e-5, f"{name} utt {n}: zq differs from the reference forward by {dz}"
+            assert dy <= WAVE_TOL, f"{name} utt {n}: waveform differs from the reference forward by {dy}"
+
+
+@pytest.mark.gpu
+def test_codectest_and_codecstatistic_end_to_end(gpu, golden_dir, tmp_path):
+    import yaml
+    from audiodec_amd import offline
+    g = _load(golden_dir, "vctk_v1_offline")
+    seed = int(g["seed"])
+    root = str(tmp_path)
+    _, enc, dec = synth.write_model(root, "vctk_v1", seed)
+    data = os.path.join(root, "corpus")
+    for sub in ("train", "test"):
+        os.makedirs(os.path.join(data, sub))
+    for n, L in enumerate(g["lengths"]):
+        for sub in ("train", "test"):
+            offline.write_wav_pcm16(os.path.join(data, sub, f"utt{n}.wav"), _audio(seed, n, int(L)), 48000)
+    _write_data_section(enc, data)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        args = types.SimpleNamespace(encoder=enc, decoder=dec)
+        tm = offline.TestMain(args)
+        tm.load_dataset("clean_test", -1)
+        tm.load_encoder()
+        tm.load_decoder()
+        tm.initial_folder("clean_test", os.path.join(root, "out"))
+        rtf = tm.run()
+        # codecStatistic
+        stat_cfg = os.path.join(root, "stat.yaml")
+        with open(stat_cfg, "w") as f:
+            yaml.safe_dump({"stats": os.path.join(root, "stats_out", "s.npy"), "analyzer": enc,
+                            "data": {"path": data, "subset": {"train": "train"}}}, f)
+        sm = offline.StatisticMain(types.SimpleNamespace(config=stat_cfg))
+        sm.load_dataset("train", -1)
+        sm.load_analyzer()
+        stats = sm.run()
+    finally:
+        os.chdir(cwd)
+    assert rtf > 0 and np.isfinite(rtf)
+    # naming rule of codecTest.py:98-114: <enc dir>-<dec dir>_<enc steps>-<dec steps>/<subset dir>
+    assert tm.outdir.endswith(os.path.join(
+        "symAD_vctk_48000_hop300-AudioDec_v1_symAD_vctk_48000_hop300_clean_200000-500000", "test"))
+    enc_o, dec_o = _oracles("vctk_v1", seed)
+    sc_rows = []
+    for n, L in enumerate(g["lengths"]):
+        out = offline.read_wav(os.path.join(tm.outdir, f"utt{n}_output.wav"))
+        x = offline.read_wav(os.path.join(data, "test", f"utt{n}.wav"))            # int16-quantised input
+        xt = torch.tensor(x, dtype=torch.float).transpose(1, 0).unsqueeze(1)
+        with torch.no_grad():
+            zq = enc_o.analyze(xt)
+            y = dec_o.synthesize(zq)
+        sc_rows.append(zq.squeeze(0).transpose(1, 0).numpy())
+        assert out.shape == (y.shape[-1], 1)
+        assert np.abs(out[:, 0] - y[0, 0].numpy()).max() <= WAVE_TOL + 2.0 / 32767           # + PCM_16 rounding / scale
+    from sklearn.preprocessing import StandardScaler
+    sc = StandardScaler()
+    for r in sc_rows:
+        sc.partial_fit(r)
+    ref = np.stack([sc.mean_, sc.scale_]).astype(np.float32)
+    assert stats.shape == (2, 64) and np.abs(stats - ref).max() <= 1e-5
+    assert np.array_equal(np.load(os.path.join(root, "stats_out", "s.npy")), stats)
