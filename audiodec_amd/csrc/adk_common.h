@@ -54,6 +54,9 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset);
 bool conv_rl_supported(const ConvArgs& a);          // rows-in-LDS kernel (stride 1, 32/64 channels per group, time-rich)
 bool conv_rl_preferred(const ConvArgs& a);          // AUTO heuristic: enough (stream, group, tile) workgroups to fill the chip
 int launch_conv_rl(const ConvArgs& a, hipStream_t s);
+bool conv_rl16_supported(const ConvArgs& a);        // split-f16 rows-in-LDS kernel (wfrag = adk_pack_weights_split16 layout)
+int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
+int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 int* flags_word();                                   // device address of the sticky debug/error flags
 int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 bool conv_mfma_supported(const ConvArgs& a);

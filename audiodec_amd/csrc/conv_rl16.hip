@@ -1,0 +1,309 @@
+// "Rows in LDS" causal conv with SPLIT-f16 operands on the f16 matrix cores (opt-in, ADK_IMPL_MFMA_ROWS_SPLIT16).
+//
+// Same structure as conv_rl.hip (one workgroup = one (stream, group, time tile), rows + history staged once),
+// but every f32 operand is carried as two f16 numbers
+//     v = hi + lo / 2048,   hi = f16(v),   lo = f16((v - hi) * 2048)          (22+ significant bits)
+// and a product sum is formed from three v_mfma_f32_32x32x16_f16 per 16 k:
+//     acc0 += A_hi * B_hi          acc1 += A_hi * B_lo + A_lo * B_hi          result = acc0 + acc1 / 2048
+// f16 x f16 products are exact in the f32 accumulator, so the only errors are the dropped lo*lo term
+// (2^-22 relative) and the 2^-22 representation error of each operand -- measured on gfx950 against fp64
+// (tools/mfma_f16_probe.hip, profiles/r1_f16_split_probe.txt): max |err| / sum|a b| = 8e-8 for K = 352..2816,
+// BELOW the 2e-7 of the f32 MFMA chain (which rounds after every product), at 3/16 of its matrix-core time.
+// f16 subnormal inputs are honoured by the instruction (same probe), |v| > 65504 would overflow hi and raises
+// device flag bit 3 (adk_debug_flags).  Weights come pre-split in fragment order (adk_pack_weights_split16).
+#include "adk_common.h"
+#include <type_traits>
+
+namespace adk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+struct Rl16Args {
+    int tt;               // time-tile length (output steps per workgroup)
+    int tiles_per_stream;
+    int mt32_per_g;
+    int span;             // (taps-1)*dilation history rows in front of a tile
+    unsigned w_bytes;
+    int* err;             // sticky device flags
+};
+
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+
+template <int ACT>
+__device__ __forceinline__ float rl16_act(float x, float slope) {
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
+    return x;
+}
+
+__device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo, bool& bad) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)x[j];
+        hi[j] = h;
+        lo[j] = (_Float16)((x[j] - (float)h) * kLoScale);
+        bad |= fabsf(x[j]) > 65504.f;
+    }
+}
+
+__device__ __forceinline__ f16x8 as_f16x8(const u32x4s& v) {
+    union { u32x4s u; f16x8 h; } c; c.u = v; return c.h;
+}
+
+// NW waves per workgroup; each wave owns work items (m-tile, pair of consecutive n-tiles) and keeps each
+// weight fragment in registers for both n-tiles.  PF = weight prefetch distance in 16-k chunks.
+template <int C, int ACT, int TAPS, int NW, int PF>
+__global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16Args rl) {
+    constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
+    constexpr int CH = C / 16;                         // 16-k chunks per tap
+    constexpr int STEPS = TAPS * CH;
+    constexpr int NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int g = blockIdx.x % a.groups;
+    const int rest = blockIdx.x / a.groups;
+    const int tile = rest % rl.tiles_per_stream;
+    const int b = rest / rl.tiles_per_stream;
+    const int t0 = tile * rl.tt;
+    const int tcur = min(rl.tt, a.t_out - t0);
+    const int n_tiles = (tcur + 31) >> 5;
+
+    // ---- stage rows [t0 - span, t0 + 32*n_tiles): activation, split into hi / lo halves ----
+    {
+        const float* xin = a.in + (size_t)b * a.in_rows * a.in_ch + a.in_choff + g * a.in_gstride;
+        const int rows_valid = rl.span + tcur;
+        const int rows_all = rl.span + 32 * n_tiles;
+        constexpr int C8 = C / 8;
+        const int items = rows_all * C8;
+        bool bad = false;
+        for (int i0 = tid; i0 < items; i0 += 2 * NT) {          // two items per pass: both loads in flight together
+            float4 u[2], v[2];
+            int rr[2], c8[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = i0 + k * NT;
+                rr[k] = i / C8; c8[k] = i - rr[k] * C8;
+                u[k] = v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < items && rr[k] < rows_valid) {
+                    int row = a.in_row0 + t0 + rr[k];
+                    row %= a.in_rows;
+                    const float4* p = reinterpret_cast<const float4*>(xin + (size_t)row * a.in_ch + 8 * c8[k]);
+                    u[k] = p[0]; v[k] = p[1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (i0 + k * NT >= items) break;
+                float4 uu = u[k], vv = v[k];
+                uu.x = rl16_act<ACT>(uu.x, a.slope); uu.y = rl16_act<ACT>(uu.y, a.slope);
+                uu.z = rl16_act<ACT>(uu.z, a.slope); uu.w = rl16_act<ACT>(uu.w, a.slope);
+                vv.x = rl16_act<ACT>(vv.x, a.slope); vv.y = rl16_act<ACT>(vv.y, a.slope);
+                vv.z = rl16_act<ACT>(vv.z, a.slope); vv.w = rl16_act<ACT>(vv.w, a.slope);
+                f16x8 hi, lo;
+                split8(uu, vv, hi, lo, bad);
+                unsigned char* d = xs + rr[k] * RS + 16 * c8[k];
+                *reinterpret_cast<f16x8*>(d) = hi;
+                *reinterpret_cast<f16x8*>(d + 2 * C) = lo;
+            }
+        }
+        if (bad) atomicOr(rl.err, 8);
+    }
+    __syncthreads();
+
+    const int m_tiles = rl.mt32_per_g;
+    const int n_pairs = (n_tiles + 1) >> 1;
+    const int items = m_tiles * n_pairs;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, rl.w_bytes, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int rot = (wave + blockIdx.x + (blockIdx.x >> 8)) % NW;
+
+    for (int item = rot; item < items; item += NW) {
+        const int mt = item / n_pairs, nt0 = 2 * (item - mt * n_pairs);
+        const bool two = nt0 + 1 < n_tiles;
+        const unsigned wbase = (unsigned)((g * m_tiles + mt) * STEPS) * 2048u;
+        f32x16 m0, m1, c0, c1;                          // main / cross-term accumulators of the two n-tiles
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
+        const unsigned char* x0 = xs + (nt0 * 32 + l31) * RS + 16 * lh;
+        const unsigned char* x1 = x0 + 32 * RS;
+
+        u32x4s ah[PF + 1], al[PF + 1];
+#pragma unroll
+        for (int s = 0; s < PF && s < STEPS; ++s) {
+            ah[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wbase + (unsigned)s * 2048u, 0);
+            al[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wbase + (unsigned)s * 2048u, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + PF < STEPS) {
+                ah[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wbase + (unsigned)(s + PF) * 2048u, 0);
+                al[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wbase + (unsigned)(s + PF) * 2048u, 0);
+            }
+            const int tap = s / CH, ch = s - tap * CH;
+            const int off = tap * a.dilation * RS + 32 * ch;
+            const f16x8 Ah = as_f16x8(ah[s % (PF + 1)]), Al = as_f16x8(al[s % (PF + 1)]);
+            const f16x8 b0h = *reinterpret_cast<const f16x8*>(x0 + off);
+            const f16x8 b0l = *reinterpret_cast<const f16x8*>(x0 + off + 2 * C);
+            if (two) {
+                const f16x8 b1h = *reinterpret_cast<const f16x8*>(x1 + off);
+                const f16x8 b1l = *reinterpret_cast<const f16x8*>(x1 + off + 2 * C);
+                m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, m0, 0, 0, 0);
+                m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1h, m1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1l, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b1h, c1, 0, 0, 0);
+            } else {
+                m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, m0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
+            }
+        }
+        // ---- epilogue: acc0 + acc1/2048, bias, residual, output activation, store ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !two) break;
+            const f32x16& am = j ? m1 : m0;
+            const f32x16& ac = j ? c1 : c0;
+            const int t = t0 + (nt0 + j) * 32 + l31;
+            if (t >= t0 + tcur) continue;
+            const float* resp = nullptr;
+            if (a.res) {
+                int rrow = a.res_cursor + t;
+                if (rrow >= a.res_rows) rrow -= a.res_rows;
+                resp = a.res + ((size_t)b * a.res_rows + rrow) * a.res_ch + a.res_choff + g * a.res_gstride;
+            }
+            int orow = a.out_cursor + t;
+            if (orow >= a.out_rows) orow -= a.out_rows;
+            float* outp = a.out + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + g * a.cout_g;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int ml = mt * 32 + 8 * qd + 4 * lh;
+                if (ml >= a.cout_g) continue;
+                float4 v = make_float4(fmaf(ac[4 * qd], kLoInv, am[4 * qd]), fmaf(ac[4 * qd + 1], kLoInv, am[4 * qd + 1]),
+                                       fmaf(ac[4 * qd + 2], kLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kLoInv, am[4 * qd + 3]));
+                if (a.bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + g * a.cout_g + ml);
+                    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                }
+                if (resp) {
+                    const float4 rr = *reinterpret_cast<const float4*>(resp + ml);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (a.act_out != ADK_ACT_NONE) {
+                    v.x = act_apply(v.x, a.act_out, 0.f); v.y = act_apply(v.y, a.act_out, 0.f);
+                    v.z = act_apply(v.z, a.act_out, 0.f); v.w = act_apply(v.w, a.act_out, 0.f);
+                }
+                *reinterpret_cast<float4*>(outp + ml) = v;
+            }
+        }
+    }
+}
+
+// w [groups*cout_g][ktot] row-major (k = tap*cin_g + ci) -> [g][m-tile 32][16-k chunk][hi | lo][lane 64][8 halfs],
+// lane (i = lane & 31, h = lane >> 5) holding W[32*mt + i][16*chunk + 8*h + 0..7]; rows beyond cout_g are zero.
+__global__ __launch_bounds__(256) void pack_split16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int groups,
+                                                           int cout_g, int ktot, int* err) {
+    const int mt32 = (cout_g + 31) / 32, chunks = ktot / 16;
+    const long long total = (long long)groups * mt32 * chunks * 512;     // (hi or lo) half-pairs: one thread per (.., lane, j)
+    bool bad = false;
+    for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(gid & 7), lane = (int)((gid >> 3) & 63);
+        const long long blk = gid >> 9;                                   // (g, mt, chunk)
+        const int ch = (int)(blk % chunks);
+        const long long gm = blk / chunks;
+        const int mt = (int)(gm % mt32), g = (int)(gm / mt32);
+        const int i = lane & 31, h = lane >> 5;
+        const int m = mt * 32 + i, k = 16 * ch + 8 * h + j;
+        float v = 0.f;
+        if (m < cout_g) v = w[((size_t)g * cout_g + m) * ktot + k];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
+        bad |= fabsf(v) > 65504.f;
+        _Float16* o = out + blk * 1024 + lane * 8 + j;
+        o[0] = hi; o[512] = lo;
+    }
+    if (bad) atomicOr(err, 8);
+}
+
+int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s) {
+    const long long total = (long long)groups * ((cout_g + 31) / 32) * (ktot / 16) * 512;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pack_split16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(out), groups, cout_g, ktot, flags_word());
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
+bool conv_rl16_supported(const ConvArgs& a) {
+    if (!a.wfrag || a.stride != 1 || a.up != 1) return false;
+    if (a.cin_g != 32 && a.cin_g != 64) return false;
+    if (a.taps != 3 && a.taps != 7 && a.taps != 11) return false;
+    if (a.cout_g % 32 != 0) return false;
+    if ((a.in_ch % 4) || (a.in_choff % 4) || (a.in_gstride % 4) || (a.out_ch % 4) || (a.out_choff % 4)) return false;
+    if (a.res && ((a.res_ch % 4) || (a.res_choff % 4) || (a.res_gstride % 4))) return false;
+    if ((reinterpret_cast<uintptr_t>(a.in) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.wfrag)) & 15) return false;
+    if (a.res && (reinterpret_cast<uintptr_t>(a.res) & 15)) return false;
+    if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return false;
+    return true;
+}
+
+namespace {
+template <int C, int NW>
+int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
+    Rl16Args rl;
+    rl.span = (a.taps - 1) * a.dilation;
+    rl.mt32_per_g = a.cout_g / 32;
+    rl.w_bytes = (unsigned)((unsigned long long)a.groups * rl.mt32_per_g * (a.ktot / 16) * 2048ull);
+    rl.err = flags_word();
+    rl.tt = tt;
+    rl.tiles_per_stream = (a.t_out + tt - 1) / tt;
+    constexpr int RS = 4 * C + 16;
+    const int tt_pad = (std::min(tt, a.t_out) + 31) / 32 * 32;
+    const size_t lds = (size_t)(rl.span + tt_pad) * RS;
+    const long long blocks = (long long)a.batch * rl.tiles_per_stream * a.groups;
+    if (blocks > 0x7fffffffLL) return fail(ADK_ERR_SHAPE, "conv: too many workgroups");
+    if (lds > 64 * 1024) return fail(ADK_ERR_SHAPE, "conv: rows-in-LDS tile exceeds 64 KiB");
+    auto go = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), lds, s, a, rl);
+        ADK_HIP_CHECK(hipGetLastError());
+        return ADK_OK;
+    };
+    constexpr int PF = 2;                             // 3 spills at the 168-VGPR budget of 3 workgroups per CU
+    auto by_taps = [&](auto act) -> int {
+        constexpr int ACT = decltype(act)::value;
+        if (a.taps == 3) return go(conv_rl16_kernel<C, ACT, 3, NW, PF>);
+        if (a.taps == 7) return go(conv_rl16_kernel<C, ACT, 7, NW, PF>);
+        return go(conv_rl16_kernel<C, ACT, 11, NW, PF>);
+    };
+    if (a.act_in == ADK_ACT_ELU) return by_taps(std::integral_constant<int, ADK_ACT_ELU>());
+    if (a.act_in == ADK_ACT_LEAKY) return by_taps(std::integral_constant<int, ADK_ACT_LEAKY>());
+    if (a.act_in == ADK_ACT_NONE) return by_taps(std::integral_constant<int, ADK_ACT_NONE>());
+    return fail(ADK_ERR_ARG, "conv: unsupported input activation for the rows-in-LDS kernel");
+}
+}  // namespace
+
+int launch_conv_rl16(const ConvArgs& a, hipStream_t s) {
+    if (a.n_total == 0) return ADK_OK;
+    const int rs = 4 * a.cin_g + 16;
+    const int span = (a.taps - 1) * a.dilation;
+    int tt = ((54000 / rs - span) / 32) * 32;
+    if (tt < 32) return fail(ADK_ERR_SHAPE, "conv: history too long for the rows-in-LDS kernel");
+    if (tt >= a.t_out) tt = a.t_out;
+    // work items of a workgroup = m-tiles x pairs of n-tiles; 5 waves when that is a multiple of 5 (the 300-step
+    // frame of a 32-channel layer: 10 n-tiles), else 4
+    const int n_tiles = (std::min(tt, a.t_out) + 31) / 32;
+    const int items = (a.cout_g / 32) * ((n_tiles + 1) / 2);
+    const bool five = items % 5 == 0;
+    if (a.cin_g == 32) return five ? launch_rl16<32, 5>(a, s, tt) : launch_rl16<32, 4>(a, s, tt);
+    return five ? launch_rl16<64, 5>(a, s, tt) : launch_rl16<64, 4>(a, s, tt);
+}
+
+}  // namespace adk

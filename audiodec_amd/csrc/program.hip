@@ -79,6 +79,10 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         if (!conv_rl_supported(a)) return fail(ADK_ERR_SHAPE, "conv: rows-in-LDS kernel needs stride 1, 32/64 channels per group, w_frag");
         return launch_conv_rl(a, s);
     }
+    if (impl == ADK_IMPL_MFMA_ROWS_SPLIT16) {
+        if (!conv_rl16_supported(a)) return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
+        return launch_conv_rl16(a, s);
+    }
     const bool want_mfma = (impl == ADK_IMPL_MFMA) || (impl == ADK_IMPL_AUTO && ok && a.groups * a.cout_g >= 32);
     if (impl == ADK_IMPL_MFMA && !ok)
         return fail(ADK_ERR_SHAPE, "conv: MFMA kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
@@ -120,6 +124,17 @@ extern "C" int adk_pack_weights_mfma(const float* w, float* out, int32_t groups,
     if (!w || !out) return fail(ADK_ERR_ARG, "adk_pack_weights_mfma: null pointer");
     if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 8) return fail(ADK_ERR_SHAPE, "adk_pack_weights_mfma: need ktot % 8 == 0");
     return launch_pack_weights(w, out, groups, cout_g, ktot, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t adk_packed_weight_floats_split16(int32_t groups, int32_t cout_g, int32_t ktot) {
+    if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 16) return -1;
+    return (int64_t)groups * ((cout_g + 31) / 32) * (ktot / 16) * 512;
+}
+
+extern "C" int adk_pack_weights_split16(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream) {
+    if (!w || !out) return fail(ADK_ERR_ARG, "adk_pack_weights_split16: null pointer");
+    if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 16) return fail(ADK_ERR_SHAPE, "adk_pack_weights_split16: need ktot % 16 == 0");
+    return launch_pack_split16(w, out, groups, cout_g, ktot, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -177,7 +192,9 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             if (o.w_off < 0 && o.wf_off < 0) return bail(ADK_ERR_ARG, "program_create: op has no weights");
             if (o.w_off >= 0 && (o.w_off % 4 || o.w_off + wn > weights_floats)) return bail(ADK_ERR_SHAPE, "program_create: weight offset out of range");
             if (o.wf_off >= 0) {
-                const long long wfn = adk_packed_weight_floats(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g);
+                const long long wfn = o.impl == ADK_IMPL_MFMA_ROWS_SPLIT16
+                    ? adk_packed_weight_floats_split16(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g)
+                    : adk_packed_weight_floats(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g);
                 if (wfn < 0 || o.wf_off % 4 || o.wf_off + wfn > weights_floats) return bail(ADK_ERR_SHAPE, "program_create: packed weight offset out of range");
             }
             if (o.b_off >= 0 && (o.b_off % 4 || o.b_off + (long long)o.conv.groups * o.conv.cout_g > weights_floats))
@@ -313,6 +330,10 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         ConvArgs a;
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
+        if (o.impl == ADK_IMPL_MFMA_ROWS_SPLIT16) {
+            snprintf(buf, n, "%s", a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>");
+            return ADK_OK;
+        }
         const bool mf = o.impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (o.impl == ADK_IMPL_MFMA || a.groups * a.cout_g >= 32);
         if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
         const bool rl = mf && ((o.impl == ADK_IMPL_MFMA_ROWS && conv_rl_supported(a)) || (o.impl == ADK_IMPL_AUTO && g_use_rl && conv_rl_preferred(a)));

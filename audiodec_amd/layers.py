@@ -18,7 +18,7 @@ import torch
 
 from . import native
 from .native import ConvDesc, RingView
-from .program import pack_conv, pack_convtr, pack_mfma, mfma_eligible
+from .program import pack_conv, pack_convtr, pack_mfma, pack_split16, mfma_eligible, split16_eligible
 
 _ACTS = {None: native.ACT_NONE, "ELU": native.ACT_ELU, "LeakyReLU": native.ACT_LEAKY, "Tanh": native.ACT_TANH}
 
@@ -71,6 +71,10 @@ class _CausalBase:
         d.act_in, d.act_in_slope, d.act_out = self.act_in, self.slope, self.act_out
         d.w = self.w_packed.data_ptr()
         d.w_frag = self.w_frag.data_ptr() if self.w_frag is not None else None
+        if self.impl == native.IMPL_MFMA_ROWS_SPLIT16:
+            if getattr(self, "w_split", None) is None:
+                raise ValueError("this layer shape has no split-f16 kernel")
+            d.w_frag = self.w_split.data_ptr()
         d.bias = self.b_packed.data_ptr() if self.b_packed is not None else None
         native.check(native.lib().adk_causal_conv(
             C.byref(d), _view(self.ring, self.rows, self.in_channels, self.cursor), _view(out, out_rows, out_ch, 0),
@@ -98,6 +102,8 @@ class CausalConv1d(_CausalBase):
         self.w_packed = rows.to(self.dev)
         ok = mfma_eligible(self.in_channels // self.groups, self.out_channels // self.groups, self.groups)
         self.w_frag = pack_mfma(rows, self.groups).to(self.dev) if ok else None
+        ok16 = split16_eligible("conv", self.in_channels // self.groups, self.out_channels // self.groups, self.kernel_size, self.stride)
+        self.w_split = pack_split16(rows, self.groups).to(self.dev) if ok16 else None
         self.b_packed = self.bias.to(self.dev) if self.bias is not None else None
         return self
 

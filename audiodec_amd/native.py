@@ -9,11 +9,11 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaudiodec_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS = 0, 1, 2, 3
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS, IMPL_MFMA_ROWS_SPLIT16 = 0, 1, 2, 3, 4
 OP_CONV, OP_RING_WRITE, OP_MEAN, OP_HIST_REPLICATE = 0, 1, 2, 3
 
 
@@ -57,6 +57,8 @@ SYMBOLS = {
     "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),
     "adk_rvq_encode": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "adk_rvq_lookup": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "adk_packed_weight_floats_split16": (C.c_int64, [_i32, _i32, _i32]),
+    "adk_pack_weights_split16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "adk_codes_frame_bytes": (C.c_int32, [_i32, _i32]),
     "adk_codes_pack": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "adk_codes_unpack": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -73,6 +73,32 @@ def pack_mfma(w_rows, groups):
     return w.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(-1)   # (g, mt, kg, h, i, e): lane = h*32 + i
 
 
+def pack_split16(w_rows, groups):
+    """Row-major GEMM rows [groups*cout_g][ktot] -> the split-f16 fragment order of adk_pack_weights_split16:
+    [g][m-tile of 32][16-k chunk][hi | lo][lane 64][8 x f16], lane (i = lane & 31, h = lane >> 5) holding
+    W[32*mt + i][16*chunk + 8*h + 0..7]; hi = f16(W), lo = f16((W - hi) * 2048).  Returned as a float32 view
+    (two halfs per float) so it can live in the weight blob."""
+    m, ktot = w_rows.shape
+    cout_g = m // groups
+    assert ktot % 16 == 0
+    mt32 = (cout_g + 31) // 32
+    w = w_rows.reshape(groups, cout_g, ktot).float()
+    if mt32 * 32 != cout_g:
+        w = torch.cat([w, torch.zeros(groups, mt32 * 32 - cout_g, ktot)], 1)
+    if float(w.abs().max()) > 65504.0:
+        raise ValueError("split-f16 weights must be below 65504 in magnitude")
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    both = torch.stack([hi, lo], 0).reshape(2, groups, mt32, 32, ktot // 16, 2, 8)     # (p, g, mt, i, ch, h, j)
+    out = both.permute(1, 2, 4, 0, 5, 3, 6).contiguous().reshape(-1)                   # (g, mt, ch, p, h, i, j)
+    return out.view(torch.float32)
+
+
+def split16_eligible(spec_kind, cin_g, cout_g, taps, stride):
+    """Layers the split-f16 rows-in-LDS kernel takes (conv_rl16_supported)."""
+    return spec_kind == "conv" and stride == 1 and cin_g in (32, 64) and taps in (3, 7, 11) and cout_g % 32 == 0
+
+
 def mfma_eligible(cin_g, cout_g, groups):
     return cin_g % 32 == 0 and cout_g % 4 == 0 and groups * cout_g >= 32
 
@@ -101,8 +127,9 @@ class Blob:
 # program builder
 # ---------------------------------------------------------------------------------------------
 class Builder:
-    def __init__(self, sd, specs, offline=False):
+    def __init__(self, sd, specs, offline=False, split16=False):
         self.sd = sd
+        self.split16 = split16          # opt-in: f16 hi/lo split operands on the f16 matrix cores where a kernel exists
         self.offline = offline          # lower Generator.forward (file-level drivers) instead of the streaming inference
         self.specs = arch.by_name(specs)
         self.blob = Blob()
@@ -198,7 +225,10 @@ class Builder:
         op.in_ch_off = op.out_ch_off = op.res_ch_off = 0
         op.rate_out = rate_out
         op.conv = d
-        if mfma_eligible(d.cin_g, d.cout_g, d.groups) and impl != native.IMPL_DIRECT:
+        if self.split16 and impl == IMPL_AUTO and split16_eligible(s.kind, d.cin_g, d.cout_g, d.taps, d.stride):
+            impl = native.IMPL_MFMA_ROWS_SPLIT16
+            op.w_off, op.wf_off = -1, self.blob.add(pack_split16(packed, d.groups))
+        elif mfma_eligible(d.cin_g, d.cout_g, d.groups) and impl != native.IMPL_DIRECT:
             op.w_off, op.wf_off = -1, self.blob.add(pack_mfma(packed, d.groups))
         else:
             op.w_off, op.wf_off = self.blob.add(packed), -1
@@ -235,10 +265,10 @@ def _res_units(b, pre, x_ring, c, rate, act, slope, out_ring_of_last):
     return x_ring
 
 
-def build_encoder(sd, p):
+def build_encoder(sd, p, split16=False):
     """Encoder.encode + Projector.encode (encoder.py:137-142, projector.py:52-54).  ext: [x, z]."""
     specs = arch.autoencoder_encoder_convs(p)
-    b = Builder(sd, specs)
+    b = Builder(sd, specs, split16=split16)
     act, slope = _act_of(p)
     hop = arch.hop_length(p)
     in_ch = p.get("input_channels", 1)
@@ -263,11 +293,11 @@ def build_encoder(sd, p):
     return b
 
 
-def build_sym_decoder(sd, p, offline=False):
+def build_sym_decoder(sd, p, offline=False, split16=False):
     """Decoder.decode / ActivateDecoder.decode (decoder.py:142-148, 203-214), or with offline=True
     Decoder.forward (:136-140: same layers, replication pad in front of the transposed convs).  ext: [zq, y]."""
     specs = arch.autoencoder_decoder_convs(p)
-    b = Builder(sd, specs, offline)
+    b = Builder(sd, specs, offline, split16)
     act, slope = _act_of(p)
     activate = p.get("codec", "audiodec") == "activate_audiodec"
     ch, ratios, strides = p.get("decode_channels", 32), p.get("dec_ratios", (16, 8, 4, 2)), p.get("dec_strides", (5, 5, 4, 3))
@@ -289,11 +319,11 @@ def build_sym_decoder(sd, p, offline=False):
     return b
 
 
-def build_hifigan(sd, p, offline=False):
+def build_hifigan(sd, p, offline=False, split16=False):
     """HiFiGAN StreamGenerator.decode (HiFiGAN.py:268-296), or with offline=True Generator.forward
     (:141-161).  ext: [zq, y]."""
     specs = arch.hifigan_convs(p)
-    b = Builder(sd, specs, offline)
+    b = Builder(sd, specs, offline, split16)
     act, slope = _act_of(p, "LeakyReLU")
     multigroup = arch.hifigan_is_multigroup(p)
     groups = p.get("groups", 1)

@@ -16,6 +16,7 @@ the reference's.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -52,6 +53,7 @@ class _StreamBase:
         self.num_streams = 1
         self.max_frames = 16
         self.offline = False
+        self.split16 = os.environ.get("ADK_SPLIT16", "0") == "1"
         self._warm = {}
 
     # ---- torch.nn.Module surface the reference's loader touches (bin/stream.py:59-61) ----
@@ -72,6 +74,15 @@ class _StreamBase:
             raise ValueError("num_streams and max_frames must be >= 1")
         if (num_streams, max_frames) != (self.num_streams, self.max_frames):
             self.num_streams, self.max_frames = int(num_streams), int(max_frames)
+            self._drop_programs()
+        return self
+
+    def set_split16(self, on=True):
+        """Opt in to (or out of) the split-precision kernels for the layers that have one: f32 operands carried
+        as f16 hi + f16 lo/2048, three f16 MFMAs per product sum, f32 accumulation (csrc/conv_rl16.hip).  Default
+        off = exact-f32 matrix-core arithmetic everywhere (env ADK_SPLIT16=1 flips the default)."""
+        if bool(on) != self.split16:
+            self.split16 = bool(on)
             self._drop_programs()
         return self
 
@@ -209,13 +220,13 @@ class AutoEncoderStreamGenerator(_StreamBase):
     # ---- lazily built device state ----
     def _encoder(self):
         if self._enc is None:
-            self._enc = program.HipProgram(program.build_encoder(self._sd, self.params), self.num_streams,
+            self._enc = program.HipProgram(program.build_encoder(self._sd, self.params, self.split16), self.num_streams,
                                            self.max_frames, self._dev())
         return self._enc
 
     def _decoder(self):
         if self._dec is None:
-            self._dec = program.HipProgram(program.build_sym_decoder(self._sd, self.params, self.offline), self.num_streams,
+            self._dec = program.HipProgram(program.build_sym_decoder(self._sd, self.params, self.offline, self.split16), self.num_streams,
                                            self.max_frames, self._dev())
         return self._dec
 
@@ -391,7 +402,7 @@ class HiFiGANStreamGenerator(_StreamBase):
 
     def _decoder(self):
         if self._dec is None:
-            self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline), self.num_streams,
+            self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline, self.split16), self.num_streams,
                                            self.max_frames, self._dev())
         return self._dec
 

@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per step (headline: 1)")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no transmitter/receiver overlap)")
     ap.add_argument("--groups", type=int, default=1, help="split the streams of a GPU into this many independently stepped groups")
+    ap.add_argument("--precision", choices=("f32", "split16"), default="f32",
+                    help="f32: exact-f32 matrix-core arithmetic everywhere (default).  split16: the opt-in kernels that carry "
+                         "each f32 operand as f16 hi + f16 lo/2048 (3 f16 MFMAs per product sum) where one exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cfg1", action="store_true", help="also time BASELINE config 1 (file round trip) on the host CPU")
     ap.add_argument("--no-op-profile", action="store_true")
@@ -211,6 +214,7 @@ def main():
 
     import __graft_entry__
     __graft_entry__.build()
+    os.environ["ADK_SPLIT16"] = "1" if args.precision == "split16" else "0"    # read by the generators at construction
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -302,7 +306,8 @@ def main():
         "metric": "48 kHz hop-300 frames/s/GPU + per-frame encode+decode latency (ms)",
         "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via split f16 (hi + lo/2048, 3 f16 MFMAs, f32 accumulate) on the rows-in-LDS layers; f32 elsewhere",
+        "data": "synthetic",
         "config": {"workload": f"{MODEL} full pipeline (symAD encoder+projector -> 8x1024 RVQ -> lookup -> AudioDec-v1 "
                                "HiFi-GAN vocoder), 48 kHz hop 300, streaming, 1 frame per stream per step "
                                "(BASELINE.json config 5 per-GPU share)",

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 4
+#define ADK_ABI_VERSION 5
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -40,7 +40,12 @@ enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_E
 enum { ADK_ACT_NONE = 0, ADK_ACT_ELU = 1, ADK_ACT_LEAKY = 2, ADK_ACT_TANH = 3 };
 
 /* kernel selection for adk_causal_conv (ADK_IMPL_AUTO in production; others for tests/benchmarks) */
-enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K implicit GEMM */, ADK_IMPL_MFMA_ROWS = 3 /* rows-in-LDS */ };
+enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K implicit GEMM */, ADK_IMPL_MFMA_ROWS = 3 /* rows-in-LDS */,
+       /* Opt-in split-precision kernels: every f32 operand is carried as f16 hi + f16 lo/2048 and a product sum is
+          formed from three f16 MFMAs (hi*hi, hi*lo, lo*hi) with f32 accumulation -- measured error vs fp64 is
+          below that of the f32 MFMA chain (profiles/r1_f16_split_probe.txt).  w_frag must then hold the
+          adk_pack_weights_split16 layout.  |operand| > 65504 raises device flag bit 3. */
+       ADK_IMPL_MFMA_ROWS_SPLIT16 = 4 };
 
 const char* adk_last_error(void);
 int adk_abi_version(void);
@@ -100,6 +105,12 @@ typedef struct {
  * adk_packed_weight_floats(groups, cout_g, ktot) floats; ktot % 8 == 0.  Done once at load time. */
 int64_t adk_packed_weight_floats(int32_t groups, int32_t cout_g, int32_t ktot);
 int adk_pack_weights_mfma(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream);
+/* Split-f16 fragment order for ADK_IMPL_*_SPLIT16: out[g][m-tile of 32][16-k chunk][hi | lo][lane 0..63][8 x f16]
+ * with lane (i = lane&31, h = lane>>5) holding W[32*mt + i][16*chunk + 8*h + 0..7], hi = f16(W),
+ * lo = f16((W - hi) * 2048); rows beyond cout_g are zero.  ktot % 16 == 0; out needs
+ * adk_packed_weight_floats_split16(groups, cout_g, ktot) floats (= 32*mt32 * ktot per group). */
+int64_t adk_packed_weight_floats_split16(int32_t groups, int32_t cout_g, int32_t ktot);
+int adk_pack_weights_split16(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream);
 
 int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
                     int32_t batch, int32_t t_out, int32_t impl, void* stream);

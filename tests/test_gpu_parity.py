@@ -40,11 +40,13 @@ def ckpt_root(tmp_path_factory):
     return str(tmp_path_factory.mktemp("audiodec_ckpt"))
 
 
-def load_audiodec(ckpt_root, model, seed, num_streams, max_frames):
+def load_audiodec(ckpt_root, model, seed, num_streams, max_frames, split16=False):
     from audiodec_amd.audiodec import AudioDec, assign_model
     synth.write_model(ckpt_root, model, seed)
     cwd = os.getcwd()
     os.chdir(ckpt_root)          # the reference's paths are cwd-relative ('exp/...', 'stats/...')
+    old = os.environ.get("ADK_SPLIT16")
+    os.environ["ADK_SPLIT16"] = "1" if split16 else "0"       # read by the generators when they are constructed
     try:
         sr, enc_ckpt, dec_ckpt = assign_model(model)
         ad = AudioDec(tx_device=DEV, rx_device=DEV, num_streams=num_streams, max_frames=max_frames)
@@ -52,6 +54,11 @@ def load_audiodec(ckpt_root, model, seed, num_streams, max_frames):
         ad.load_receiver(enc_ckpt, dec_ckpt)
     finally:
         os.chdir(cwd)
+        if old is None:
+            del os.environ["ADK_SPLIT16"]
+        else:
+            os.environ["ADK_SPLIT16"] = old
+    assert ad.tx_encoder.split16 == split16 and ad.decoder.split16 == split16
     return ad
 
 
@@ -128,6 +135,8 @@ def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
     impls = [native.IMPL_DIRECT, native.IMPL_MFMA]
     if s == 1 and cin // gr in (32, 64) and (cout // gr) % 32 == 0 and L >= 24:
         impls.append(native.IMPL_MFMA_ROWS)              # the rows-in-LDS kernel takes this shape
+    if s == 1 and cin // gr in (32, 64) and (cout // gr) % 32 == 0 and k in (3, 7, 11):
+        impls.append(native.IMPL_MFMA_ROWS_SPLIT16)      # ... and its split-f16 variant
     for impl in impls:
         m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
         m.set_activation(act, 0.1)
@@ -139,6 +148,43 @@ def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
         for m in mods:
             y = m.inference(x).cpu()
             assert float((y - ref).abs().max()) < 2e-5, (m.impl, step)
+
+
+def test_split16_weight_packing_kernel_matches_host_packing(gpu):
+    import ctypes as ct
+    from audiodec_amd import native, program
+    g = torch.Generator().manual_seed(5)
+    for groups, cout_g, ktot in ((3, 32, 352), (1, 64, 448), (3, 64, 704), (1, 96, 96)):
+        w = torch.randn(groups * cout_g, ktot, generator=g) * 0.2
+        w[0, 0], w[1, 1] = 1e-7, 3.1e-5                  # f16-subnormal hi parts
+        host = program.pack_split16(w, groups)
+        n = native.lib().adk_packed_weight_floats_split16(groups, cout_g, ktot)
+        assert n == host.numel()
+        out = torch.empty(n, device=gpu)
+        wd = w.to(gpu)
+        native.check(native.lib().adk_pack_weights_split16(ct.c_void_p(wd.data_ptr()), ct.c_void_p(out.data_ptr()), groups, cout_g, ktot,
+                                                           native.current_stream(gpu)), "adk_pack_weights_split16")
+        assert torch.equal(out.cpu().view(torch.int32), host.view(torch.int32))
+    assert native.lib().adk_packed_weight_floats_split16(1, 32, 100) == -1
+
+
+def test_split16_overflow_raises_device_flag(gpu):
+    import ctypes as ct
+    from audiodec_amd import layers, native
+    m = layers.CausalConv1d(32, 32, 3, device=gpu, batch=1, max_len=64).load(torch.randn(32, 32, 3) * 0.1, torch.zeros(32))
+    m.impl = native.IMPL_MFMA_ROWS_SPLIT16
+    flags = ct.c_int32(0)
+    native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
+    x = torch.randn(1, 32, 64)
+    m.inference(x)
+    native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
+    assert flags.value == 0
+    x[0, 3, 10] = 7.0e4                                  # beyond the f16 range
+    m.inference(x)
+    native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
+    assert flags.value & 8
+    native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
+    assert flags.value == 0                              # sticky until read, then cleared
 
 
 # ------------------------------------------------------------------------------------------------
@@ -164,12 +210,16 @@ def run_hip(ad, audio, chunks):
 @pytest.mark.parametrize("name,max_frames", [("vctk_sym_stream", 2), ("vctk_v1_stream", 4), ("libritts_sym_file", 16),
                                              ("vctk_v2_stream", 2), ("vctk_v0_stream", 2), ("vctk_activate_sym_stream", 2),
                                              ("vctk_c16h320_sym_stream", 2)])
-def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames):
+@pytest.mark.parametrize("split16", [False, True], ids=["f32", "split16"])
+def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames, split16):
     g = _load(golden_dir, name)
     model, seed, n = str(g["model"]), int(g["seed"]), int(g["n_streams"])
     chunks = golden_chunks(g)
     audio = np.stack([synth.synth_audio(seed, s, sum(chunks)) for s in range(n)])
-    ad = load_audiodec(ckpt_root, model, seed, n, max_frames)
+    ad = load_audiodec(ckpt_root, model, seed, n, max_frames, split16)
+    if split16:                                              # the opt-in kernels really are in the programs
+        kinds = [ad.decoder._decoder().describe_op(i, 1) for i in range(ad.decoder._decoder().n_ops)]
+        assert any(k.startswith("conv_rl16") for k in kinds), kinds
     z, idx, zq, y = run_hip(ad, audio, chunks)
     assert z.shape == g["z"].shape and y.shape == g["y"].shape and idx.shape == g["idx"].shape
     assert np.abs(z - g["z"]).max() < WAVE_TOL

@@ -13,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from audiodec_amd import native  # noqa: E402
 from audiodec_amd.native import ConvDesc, RingView  # noqa: E402
-from audiodec_amd.program import pack_mfma  # noqa: E402
+from audiodec_amd.program import pack_mfma, pack_split16  # noqa: E402
 
 SHAPES = {  # cin_g, cout_g, groups, taps, stride, dil, t_out, up, act
     "s0": (256, 256, 3, 11, 1, 5, 5, 1, 2), "s1": (128, 128, 3, 11, 1, 5, 25, 1, 2),
@@ -31,7 +31,7 @@ def view(t, rows, ch, cur):
     return v
 
 
-def run(shape, cfg, B, iters, impl=native.IMPL_MFMA):
+def run(shape, cfg, B, iters, impl=native.IMPL_MFMA, check=False):
     lib = native.lib()
     cin_g, cout_g, groups, taps, stride, dil, t_out, up, act = SHAPES[shape]
     dev = "cuda:0"
@@ -48,7 +48,7 @@ def run(shape, cfg, B, iters, impl=native.IMPL_MFMA):
     d.cin_g, d.cout_g, d.groups, d.taps, d.stride, d.dilation, d.hist = cin_g, cout_g, groups, taps, stride, dil, hist
     d.up, d.cout_real, d.in_group_stride, d.res_group_stride = up, cout_real, cin_g, cout_g
     d.act_in, d.act_in_slope, d.act_out = act, 0.1, 0
-    wf = pack_mfma(w.cpu(), groups).to(dev)
+    wf = (pack_split16(w.cpu(), groups) if impl == native.IMPL_MFMA_ROWS_SPLIT16 else pack_mfma(w.cpu(), groups)).to(dev)
     d.w, d.w_frag, d.bias = w.data_ptr(), wf.data_ptr(), bias.data_ptr()
     lib.adk_set_conv_cfg(cfg)
     st = native.current_stream(dev)
@@ -56,6 +56,14 @@ def run(shape, cfg, B, iters, impl=native.IMPL_MFMA):
 
     def go():
         native.check(lib.adk_causal_conv(C.byref(d), vin, vout, vres, B, t_out, impl, st), "conv")
+    if check:
+        go()
+        got = out.clone()
+        wf2 = pack_mfma(w.cpu(), groups).to(dev)
+        d.w_frag = wf2.data_ptr()
+        native.check(lib.adk_causal_conv(C.byref(d), vin, vout, vres, B, t_out, native.IMPL_MFMA, st), "conv")
+        print(f"   max|impl {impl} - stream-K f32| = {float((got - out).abs().max()):.3e}  (|out|max {float(out.abs().max()):.2f})")
+        d.w_frag = wf.data_ptr()
     for _ in range(5):
         go()
     torch.cuda.synchronize()
@@ -76,9 +84,10 @@ if __name__ == "__main__":
     ap.add_argument("--cfg", default="-1")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--impl", type=int, default=native.IMPL_MFMA, help="2 stream-K, 3 rows-in-LDS, 0 auto")
+    ap.add_argument("--impl", type=int, default=native.IMPL_MFMA, help="2 stream-K, 3 rows-in-LDS, 4 split-f16 rows-in-LDS, 0 auto")
+    ap.add_argument("--check", action="store_true", help="compare the output with the f32 stream-K kernel")
     a = ap.parse_args()
     for sh in a.shape.split(","):
         for cfg in a.cfg.split(","):
-            us, tf = run(sh, int(cfg), a.batch, a.iters, a.impl)
+            us, tf = run(sh, int(cfg), a.batch, a.iters, a.impl, a.check)
             print(f"{sh:5s} impl {a.impl} cfg {cfg:>2s}  B={a.batch}  {us:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
