@@ -56,6 +56,8 @@ bool conv_rl_preferred(const ConvArgs& a);          // AUTO heuristic: enough (s
 int launch_conv_rl(const ConvArgs& a, hipStream_t s);
 bool conv_rl16_supported(const ConvArgs& a);        // split-f16 rows-in-LDS kernel (wfrag = adk_pack_weights_split16 layout)
 int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
+int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
+int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 int* flags_word();                                   // device address of the sticky debug/error flags
 int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);

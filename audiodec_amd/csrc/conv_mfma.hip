@@ -14,8 +14,15 @@
 // long K.  Hence:
 //   * grid = G persistent workgroups (G = 256 CUs x occupancy); the (tile, K-chunk) work units are
 //     split EVENLY over them in tile order (stream-K).  A workgroup that covers a whole tile writes
-//     it out directly; tiles cut by a range boundary leave raw partial accumulators in a workspace
-//     and a small fix-up kernel adds them in fixed (deterministic) order and runs the epilogue.
+//     it out directly; a tile cut by range boundaries is finished by the workgroup that holds its first
+//     chunk (the owner): the later ranges publish their raw partial accumulators FIRST THING in their run
+//     (write-through stores + one flag), the owner adds them in range order (deterministic) at the END of
+//     its run and runs the epilogue.  Progress: workgroups are dispatched in blockIdx order and an owner
+//     only ever waits for higher ranges, which publish before doing anything else -- so whenever a slot
+//     frees, the next workgroup to start is exactly one some spinner may be waiting for; the spin is
+//     bounded anyway (flag bit 1) so a broken assumption cannot hang the device.  (A wait-free variant --
+//     every contributor publishes, the last arriver reduces -- was measured 3.4 us per launch slower: the
+//     owner's partial then also takes the write-through round trip on the critical path.)
 //   * ranges are XCD-contiguous (block b -> range (b%8)*(G/8)+b/8) and tiles are ordered with the
 //     M-tile fastest, so the workgroups sharing one XCD's L2 walk neighbouring tiles: the weight
 //     panel of a group stays L2-resident, the activations stream from HBM once.
@@ -30,12 +37,22 @@
 //   * each lane reads 4 consecutive k per ds_read_b128 and feeds 4 MFMAs per accumulator (the k
 //     order inside a chunk is permuted identically for both operands: only the order of the exact
 //     f32 sum changes).
+//
+// SPLIT = true is the opt-in split-precision variant (ADK_IMPL_SPLIT16*): same schedule, same fix-up, but
+// the staged X chunk is stored as f16 hi / f16 lo*2048 halves (same LDS bytes), the weights come in the
+// adk_pack_weights_split16 layout (same 8 KiB per (32 rows, 64 k)), and a 64-deep chunk is 4 x 3
+// v_mfma_f32_32x32x16_f16 per accumulator pair (hi*hi -> main, hi*lo + lo*hi -> cross) instead of
+// 32 v_mfma_f32_32x32x2_f32; main + cross/2048 is formed when a segment ends.  See conv_rl16.hip for the
+// error analysis.
 #include "adk_common.h"
 #include <cstdlib>
 
 namespace adk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+constexpr float kSkLoScale = 2048.f, kSkLoInv = 1.f / 2048.f;
 
 constexpr int KC = 64;    // K chunk: two 32-channel half-chunks (each one tap x 32 channels)
 constexpr int LDK = 68;   // padded LDS row stride (floats): conflict-free ds_write_b128 / ds_read_b128
@@ -51,7 +68,7 @@ struct SkArgs {
     int mt32_per_g;       // 32-row fragment tiles per group
     unsigned in_bytes, w_bytes;   // buffer-descriptor extents of the input arena view / packed weights
     unsigned ws_bytes;            // extent of the partial workspace
-    int* err;                     // device error word (bit 1: a publish flag never arrived)
+    int* err;                     // device error word (bit 1: a publish flag never arrived; bit 3: split-f16 operand overflow)
     float inv_t_out;
     long long total;      // tiles * nchunks
 };
@@ -141,7 +158,7 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
 // MFMA bursts is exposed, so per-chunk addressing is reduced to buffer loads with one per-thread VGPR
 // offset per staged column (updated by adds) and scalar offsets for the weight stream; columns past
 // N and the zero-padded K tail read out of bounds (= 0) instead of branching.
-template <int WGM, int WGN, int NJ, int ACT>
+template <int WGM, int WGN, int NJ, int ACT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) {
     constexpr int BN = 32 * NJ * WGN;
     constexpr int RB = BN / 16;                       // staging rounds: 16 columns x 16 quads per round
@@ -226,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
 #pragma unroll
         for (int q = 0; q < 8; ++q) a_nxt[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
     };
+    bool ovf = false;                                   // SPLIT: an operand beyond the f16 range was staged
     auto lstore = [&](int buf) {
         float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
@@ -233,15 +251,35 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
             float4 v = rb[rr];
             v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
             v.z = act_in_apply<ACT>(v.z, a.slope); v.w = act_in_apply<ACT>(v.w, a.slope);
-            *reinterpret_cast<float4*>(Bb + (srow + 16 * rr) * LDK + 4 * quad) = v;
+            if constexpr (SPLIT) {
+                // column row = [64 halfs hi][64 halfs lo][16 B pad]; this thread's 4 floats -> 2 x 8 bytes
+                f16x4s hi, lo;
+                const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)x[e];
+                    hi[e] = h; lo[e] = (_Float16)((x[e] - (float)h) * kSkLoScale);
+                    ovf |= fabsf(x[e]) > 65504.f;
+                }
+                unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + 16 * rr) * LDK) + 8 * quad;
+                *reinterpret_cast<f16x4s*>(d) = hi;
+                *reinterpret_cast<f16x4s*>(d + 128) = lo;
+            } else {
+                *reinterpret_cast<float4*>(Bb + (srow + 16 * rr) * LDK + 4 * quad) = v;
+            }
         }
     };
 
     f32x16 acc[NJ];
+    f32x16 accx[SPLIT ? NJ : 1];                       // SPLIT: cross-term accumulators (scaled by 2048)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < (SPLIT ? NJ : 1); ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accx[j][e] = 0.f;
 
     // ---- prologue: first chunk into LDS buffer 0 ----
     int tile = (int)(u0 / sk.nchunks);
@@ -267,7 +305,26 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         }
         // -- MFMAs on the current chunk --
         const float* Bb = Bs + cur * BN * LDK + (wn * NJ * 32 + l31) * LDK + 4 * lh;
-        {
+        if constexpr (SPLIT) {
+            const unsigned char* Bh = reinterpret_cast<const unsigned char*>(Bb);     // + 4*lh floats = 16*lh bytes: this lane's 8 halfs
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                union { float4 f; f16x8s h; } ah, al;
+                ah.f = a_cur[2 * st]; al.f = a_cur[2 * st + 1];
+                f16x8s bh[NJ], bl[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st);
+                    bl[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st + 128);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bl[j], accx[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bh[j], accx[j], 0, 0, 0);
+            }
+        } else {
             float4 bv[2][NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bv[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDK);
@@ -294,6 +351,12 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         if (kc == sk.nchunks - 1 || !has_next) {
             const int ml0 = (cur_mt * WGM + wm) * 32;
             const int n0w = cur_nt * BN + wn * NJ * 32;
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc[j][e] = fmaf(accx[j][e], kSkLoInv, acc[j][e]); accx[j][e] = 0.f; }
+            }
             const bool seg_first = (seg_start_kc == 0);            // segment holds the tile's first chunk
             const bool seg_last = (kc == sk.nchunks - 1);          // ... and its last chunk
             if (!seg_first) {
@@ -360,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         for (int q = 0; q < 8; ++q) a_cur[q] = a_nxt[q];
         if (++kc == sk.nchunks) { kc = 0; ++tile; }
     }
+    if constexpr (SPLIT) { if (ovf) atomicOr(sk.err, 8); }
 }
 
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
@@ -402,7 +466,7 @@ int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuri
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
 int g_min_units = 2;       // minimum K chunks per workgroup (ADK_CONV_MIN_UNITS; 2 measured best at 256 streams)
 
-template <int WGM, int WGN, int NJ>
+template <int WGM, int WGN, int NJ, bool SPLIT>
 int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN;
     constexpr size_t lds = 2ull * BN * LDK * sizeof(float);
@@ -440,18 +504,18 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
     }
     if (a.act_in == ADK_ACT_ELU)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT>), dim3(sk.G), dim3(256), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_LEAKY)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT>), dim3(sk.G), dim3(256), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_NONE)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT>), dim3(sk.G), dim3(256), lds, s, a, sk);
     else
         return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
     ADK_HIP_CHECK(hipGetLastError());
@@ -487,12 +551,36 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (a.n_total == 0) return ADK_OK;
     (void)conv_mfma_workspace_bytes(nullptr);
     switch (conv_mfma_pick(a)) {
-        case 0: return launch_cfg<4, 1, 2>(a, s, ws);
-        case 1: return launch_cfg<4, 1, 4>(a, s, ws);
-        case 2: return launch_cfg<2, 2, 1>(a, s, ws);
-        case 3: return launch_cfg<2, 2, 2>(a, s, ws);
-        case 4: return launch_cfg<1, 4, 1>(a, s, ws);
-        default: return launch_cfg<1, 4, 2>(a, s, ws);
+        case 0: return launch_cfg<4, 1, 2, false>(a, s, ws);
+        case 1: return launch_cfg<4, 1, 4, false>(a, s, ws);
+        case 2: return launch_cfg<2, 2, 1, false>(a, s, ws);
+        case 3: return launch_cfg<2, 2, 2, false>(a, s, ws);
+        case 4: return launch_cfg<1, 4, 1, false>(a, s, ws);
+        default: return launch_cfg<1, 4, 2, false>(a, s, ws);
+    }
+}
+
+// split-f16 variant: wfrag = adk_pack_weights_split16 layout
+int conv_sk16_pick(const ConvArgs& a) {
+    if (g_forced_cfg == -2) { const char* e = getenv("ADK_CONV_CFG"); g_forced_cfg = e ? atoi(e) : -1; }
+    if (g_forced_cfg >= 0 && g_forced_cfg <= 5) return g_forced_cfg;
+    // with the matrix-core time cut to 3/16 the weight / activation re-reads weigh more: 128-row tiles (each X chunk
+    // staged once per 128 output channels) win when that still leaves >= 256 tiles (measured: grouped 128-channel
+    // vocoder stage 47.7 vs 55.2 us; the 100-tile encoder block loses, 34.6 vs 28.2 us)
+    if (a.cout_g % 128 == 0 && (long long)(a.cout_g / 128) * ((a.n_total + 63) / 64) * a.groups >= 256) return 0;
+    return (a.cout_g % 64 == 0) ? 2 : 4;
+}
+
+int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
+    if (a.n_total == 0) return ADK_OK;
+    (void)conv_mfma_workspace_bytes(nullptr);
+    switch (conv_sk16_pick(a)) {
+        case 0: return launch_cfg<4, 1, 2, true>(a, s, ws);
+        case 1: return launch_cfg<4, 1, 4, true>(a, s, ws);
+        case 2: return launch_cfg<2, 2, 1, true>(a, s, ws);
+        case 3: return launch_cfg<2, 2, 2, true>(a, s, ws);
+        case 4: return launch_cfg<1, 4, 1, true>(a, s, ws);
+        default: return launch_cfg<1, 4, 2, true>(a, s, ws);
     }
 }
 

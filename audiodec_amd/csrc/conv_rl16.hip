@@ -1,4 +1,4 @@
-// "Rows in LDS" causal conv with SPLIT-f16 operands on the f16 matrix cores (opt-in, ADK_IMPL_MFMA_ROWS_SPLIT16).
+// "Rows in LDS" causal conv with SPLIT-f16 operands on the f16 matrix cores (opt-in, ADK_IMPL_SPLIT16 / ADK_IMPL_SPLIT16_ROWS).
 //
 // Same structure as conv_rl.hip (one workgroup = one (stream, group, time tile), rows + history staged once),
 // but every f32 operand is carried as two f16 numbers
@@ -25,6 +25,7 @@ struct Rl16Args {
     int tiles_per_stream;
     int mt32_per_g;
     int span;             // (taps-1)*dilation history rows in front of a tile
+    int ksteps;           // 16-k chunks per m-tile in the packed weights (K padded to a multiple of 64)
     unsigned w_bytes;
     int* err;             // sticky device flags
 };
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
     for (int item = rot; item < items; item += NW) {
         const int mt = item / n_pairs, nt0 = 2 * (item - mt * n_pairs);
         const bool two = nt0 + 1 < n_tiles;
-        const unsigned wbase = (unsigned)((g * m_tiles + mt) * STEPS) * 2048u;
+        const unsigned wbase = (unsigned)((g * m_tiles + mt) * rl.ksteps) * 2048u;
         f32x16 m0, m1, c0, c1;                          // main / cross-term accumulators of the two n-tiles
 #pragma unroll
         for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
@@ -208,10 +209,11 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
 }
 
 // w [groups*cout_g][ktot] row-major (k = tap*cin_g + ci) -> [g][m-tile 32][16-k chunk][hi | lo][lane 64][8 halfs],
-// lane (i = lane & 31, h = lane >> 5) holding W[32*mt + i][16*chunk + 8*h + 0..7]; rows beyond cout_g are zero.
+// lane (i = lane & 31, h = lane >> 5) holding W[32*mt + i][16*chunk + 8*h + 0..7]; rows beyond cout_g and the K tail
+// (K padded to a multiple of 64, like adk_pack_weights_mfma) are zero.
 __global__ __launch_bounds__(256) void pack_split16_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int groups,
                                                            int cout_g, int ktot, int* err) {
-    const int mt32 = (cout_g + 31) / 32, chunks = ktot / 16;
+    const int mt32 = (cout_g + 31) / 32, chunks = (ktot + 63) / 64 * 4;
     const long long total = (long long)groups * mt32 * chunks * 512;     // (hi or lo) half-pairs: one thread per (.., lane, j)
     bool bad = false;
     for (long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long long)gridDim.x * blockDim.x) {
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void pack_split16_kernel(const float* __restri
         const int i = lane & 31, h = lane >> 5;
         const int m = mt * 32 + i, k = 16 * ch + 8 * h + j;
         float v = 0.f;
-        if (m < cout_g) v = w[((size_t)g * cout_g + m) * ktot + k];
+        if (m < cout_g && k < ktot) v = w[((size_t)g * cout_g + m) * ktot + k];
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)((v - (float)hi) * kLoScale);
         bad |= fabsf(v) > 65504.f;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void pack_split16_kernel(const float* __restri
 }
 
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s) {
-    const long long total = (long long)groups * ((cout_g + 31) / 32) * (ktot / 16) * 512;
+    const long long total = (long long)groups * ((cout_g + 31) / 32) * ((ktot + 63) / 64 * 4) * 512;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(pack_split16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, reinterpret_cast<_Float16*>(out), groups, cout_g, ktot, flags_word());
@@ -261,7 +263,8 @@ int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
     Rl16Args rl;
     rl.span = (a.taps - 1) * a.dilation;
     rl.mt32_per_g = a.cout_g / 32;
-    rl.w_bytes = (unsigned)((unsigned long long)a.groups * rl.mt32_per_g * (a.ktot / 16) * 2048ull);
+    rl.ksteps = (a.ktot + 63) / 64 * 4;
+    rl.w_bytes = (unsigned)((unsigned long long)a.groups * rl.mt32_per_g * rl.ksteps * 2048ull);
     rl.err = flags_word();
     rl.tt = tt;
     rl.tiles_per_stream = (a.t_out + tt - 1) / tt;

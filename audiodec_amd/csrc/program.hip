@@ -79,9 +79,16 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         if (!conv_rl_supported(a)) return fail(ADK_ERR_SHAPE, "conv: rows-in-LDS kernel needs stride 1, 32/64 channels per group, w_frag");
         return launch_conv_rl(a, s);
     }
-    if (impl == ADK_IMPL_MFMA_ROWS_SPLIT16) {
-        if (!conv_rl16_supported(a)) return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
-        return launch_conv_rl16(a, s);
+    if (impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK) {
+        // split-f16 kernels (w_frag in the adk_pack_weights_split16 layout): rows-in-LDS when it fills the chip, else stream-K
+        if (impl == ADK_IMPL_SPLIT16_ROWS && !conv_rl16_supported(a))
+            return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
+        if (impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_supported(a) && conv_rl_preferred(a)))
+            return launch_conv_rl16(a, s);
+        if (!ok) return fail(ADK_ERR_SHAPE, "conv: split-f16 kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
+        int rc = ensure_workspace(ws);
+        if (rc != ADK_OK) return rc;
+        return launch_conv_sk16(a, s, ws);
     }
     const bool want_mfma = (impl == ADK_IMPL_MFMA) || (impl == ADK_IMPL_AUTO && ok && a.groups * a.cout_g >= 32);
     if (impl == ADK_IMPL_MFMA && !ok)
@@ -128,7 +135,7 @@ extern "C" int adk_pack_weights_mfma(const float* w, float* out, int32_t groups,
 
 extern "C" int64_t adk_packed_weight_floats_split16(int32_t groups, int32_t cout_g, int32_t ktot) {
     if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 16) return -1;
-    return (int64_t)groups * ((cout_g + 31) / 32) * (ktot / 16) * 512;
+    return (int64_t)groups * ((cout_g + 31) / 32) * ((ktot + 63) / 64 * 4) * 512;
 }
 
 extern "C" int adk_pack_weights_split16(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream) {
@@ -192,9 +199,9 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             if (o.w_off < 0 && o.wf_off < 0) return bail(ADK_ERR_ARG, "program_create: op has no weights");
             if (o.w_off >= 0 && (o.w_off % 4 || o.w_off + wn > weights_floats)) return bail(ADK_ERR_SHAPE, "program_create: weight offset out of range");
             if (o.wf_off >= 0) {
-                const long long wfn = o.impl == ADK_IMPL_MFMA_ROWS_SPLIT16
-                    ? adk_packed_weight_floats_split16(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g)
-                    : adk_packed_weight_floats(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g);
+                const bool s16 = o.impl == ADK_IMPL_SPLIT16 || o.impl == ADK_IMPL_SPLIT16_ROWS || o.impl == ADK_IMPL_SPLIT16_SK;
+                const long long wfn = s16 ? adk_packed_weight_floats_split16(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g)
+                                          : adk_packed_weight_floats(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g);
                 if (wfn < 0 || o.wf_off % 4 || o.wf_off + wfn > weights_floats) return bail(ADK_ERR_SHAPE, "program_create: packed weight offset out of range");
             }
             if (o.b_off >= 0 && (o.b_off % 4 || o.b_off + (long long)o.conv.groups * o.conv.cout_g > weights_floats))
@@ -330,8 +337,11 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         ConvArgs a;
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
-        if (o.impl == ADK_IMPL_MFMA_ROWS_SPLIT16) {
-            snprintf(buf, n, "%s", a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>");
+        if (o.impl == ADK_IMPL_SPLIT16 || o.impl == ADK_IMPL_SPLIT16_ROWS || o.impl == ADK_IMPL_SPLIT16_SK) {
+            if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
+            const bool rows = o.impl == ADK_IMPL_SPLIT16_ROWS || (o.impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_supported(a) && conv_rl_preferred(a));
+            std::string nm = rows ? (a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>") : std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
+            snprintf(buf, n, "%s", nm.c_str());
             return ADK_OK;
         }
         const bool mf = o.impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (o.impl == ADK_IMPL_MFMA || a.groups * a.cout_g >= 32);

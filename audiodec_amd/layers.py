@@ -71,7 +71,7 @@ class _CausalBase:
         d.act_in, d.act_in_slope, d.act_out = self.act_in, self.slope, self.act_out
         d.w = self.w_packed.data_ptr()
         d.w_frag = self.w_frag.data_ptr() if self.w_frag is not None else None
-        if self.impl == native.IMPL_MFMA_ROWS_SPLIT16:
+        if self.impl in (native.IMPL_SPLIT16, native.IMPL_SPLIT16_ROWS, native.IMPL_SPLIT16_SK):
             if getattr(self, "w_split", None) is None:
                 raise ValueError("this layer shape has no split-f16 kernel")
             d.w_frag = self.w_split.data_ptr()
@@ -102,7 +102,7 @@ class CausalConv1d(_CausalBase):
         self.w_packed = rows.to(self.dev)
         ok = mfma_eligible(self.in_channels // self.groups, self.out_channels // self.groups, self.groups)
         self.w_frag = pack_mfma(rows, self.groups).to(self.dev) if ok else None
-        ok16 = split16_eligible("conv", self.in_channels // self.groups, self.out_channels // self.groups, self.kernel_size, self.stride)
+        ok16 = split16_eligible(self.in_channels // self.groups, self.out_channels // self.groups, self.groups)
         self.w_split = pack_split16(rows, self.groups).to(self.dev) if ok16 else None
         self.b_packed = self.bias.to(self.dev) if self.bias is not None else None
         return self
@@ -140,6 +140,7 @@ class CausalConvTranspose1d(_CausalBase):
         self.w_packed = rows.to(self.dev)
         ok = mfma_eligible(self.in_channels, self.stride * self.out_channels, 1)
         self.w_frag = pack_mfma(rows, 1).to(self.dev) if ok else None
+        self.w_split = pack_split16(rows, 1).to(self.dev) if split16_eligible(self.in_channels, self.stride * self.out_channels, 1) else None
         self.b_packed = self.bias.repeat(self.stride).to(self.dev) if self.bias is not None else None
         return self
 

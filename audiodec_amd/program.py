@@ -76,8 +76,9 @@ def pack_mfma(w_rows, groups):
 def pack_split16(w_rows, groups):
     """Row-major GEMM rows [groups*cout_g][ktot] -> the split-f16 fragment order of adk_pack_weights_split16:
     [g][m-tile of 32][16-k chunk][hi | lo][lane 64][8 x f16], lane (i = lane & 31, h = lane >> 5) holding
-    W[32*mt + i][16*chunk + 8*h + 0..7]; hi = f16(W), lo = f16((W - hi) * 2048).  Returned as a float32 view
-    (two halfs per float) so it can live in the weight blob."""
+    W[32*mt + i][16*chunk + 8*h + 0..7]; hi = f16(W), lo = f16((W - hi) * 2048); rows beyond cout_g and the K
+    tail (K padded to a multiple of 64) are zero.  Returned as a float32 view (two halfs per float) so it can
+    live in the weight blob."""
     m, ktot = w_rows.shape
     cout_g = m // groups
     assert ktot % 16 == 0
@@ -85,6 +86,10 @@ def pack_split16(w_rows, groups):
     w = w_rows.reshape(groups, cout_g, ktot).float()
     if mt32 * 32 != cout_g:
         w = torch.cat([w, torch.zeros(groups, mt32 * 32 - cout_g, ktot)], 1)
+    kpad = (ktot + 63) // 64 * 64                      # same 64-deep chunking as pack_mfma
+    if kpad != ktot:
+        w = torch.cat([w, torch.zeros(groups, mt32 * 32, kpad - ktot)], 2)
+        ktot = kpad
     if float(w.abs().max()) > 65504.0:
         raise ValueError("split-f16 weights must be below 65504 in magnitude")
     hi = w.half()
@@ -94,9 +99,9 @@ def pack_split16(w_rows, groups):
     return out.view(torch.float32)
 
 
-def split16_eligible(spec_kind, cin_g, cout_g, taps, stride):
-    """Layers the split-f16 rows-in-LDS kernel takes (conv_rl16_supported)."""
-    return spec_kind == "conv" and stride == 1 and cin_g in (32, 64) and taps in (3, 7, 11) and cout_g % 32 == 0
+def split16_eligible(cin_g, cout_g, groups):
+    """Layers that have a split-f16 kernel: everything the matrix-core kernels take (conv_sk16 / conv_rl16)."""
+    return mfma_eligible(cin_g, cout_g, groups) and cin_g % 32 == 0
 
 
 def mfma_eligible(cin_g, cout_g, groups):
@@ -225,8 +230,8 @@ class Builder:
         op.in_ch_off = op.out_ch_off = op.res_ch_off = 0
         op.rate_out = rate_out
         op.conv = d
-        if self.split16 and impl == IMPL_AUTO and split16_eligible(s.kind, d.cin_g, d.cout_g, d.taps, d.stride):
-            impl = native.IMPL_MFMA_ROWS_SPLIT16
+        if self.split16 and impl == IMPL_AUTO and split16_eligible(d.cin_g, d.cout_g, d.groups):
+            impl = native.IMPL_SPLIT16
             op.w_off, op.wf_off = -1, self.blob.add(pack_split16(packed, d.groups))
         elif mfma_eligible(d.cin_g, d.cout_g, d.groups) and impl != native.IMPL_DIRECT:
             op.w_off, op.wf_off = -1, self.blob.add(pack_mfma(packed, d.groups))

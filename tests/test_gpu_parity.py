@@ -136,7 +136,8 @@ def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
     if s == 1 and cin // gr in (32, 64) and (cout // gr) % 32 == 0 and L >= 24:
         impls.append(native.IMPL_MFMA_ROWS)              # the rows-in-LDS kernel takes this shape
     if s == 1 and cin // gr in (32, 64) and (cout // gr) % 32 == 0 and k in (3, 7, 11):
-        impls.append(native.IMPL_MFMA_ROWS_SPLIT16)      # ... and its split-f16 variant
+        impls.append(native.IMPL_SPLIT16_ROWS)           # ... and its split-f16 variant
+    impls.append(native.IMPL_SPLIT16_SK)                 # split-f16 stream-K takes every matrix-core shape
     for impl in impls:
         m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
         m.set_activation(act, 0.1)
@@ -172,7 +173,7 @@ def test_split16_overflow_raises_device_flag(gpu):
     import ctypes as ct
     from audiodec_amd import layers, native
     m = layers.CausalConv1d(32, 32, 3, device=gpu, batch=1, max_len=64).load(torch.randn(32, 32, 3) * 0.1, torch.zeros(32))
-    m.impl = native.IMPL_MFMA_ROWS_SPLIT16
+    m.impl = native.IMPL_SPLIT16_ROWS
     flags = ct.c_int32(0)
     native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
     x = torch.randn(1, 32, 64)
@@ -180,11 +181,13 @@ def test_split16_overflow_raises_device_flag(gpu):
     native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
     assert flags.value == 0
     x[0, 3, 10] = 7.0e4                                  # beyond the f16 range
-    m.inference(x)
-    native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
-    assert flags.value & 8
-    native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
-    assert flags.value == 0                              # sticky until read, then cleared
+    for impl in (native.IMPL_SPLIT16_ROWS, native.IMPL_SPLIT16_SK):
+        m.impl = impl
+        m.inference(x)
+        native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
+        assert flags.value & 8, impl
+        native.check(native.lib().adk_debug_flags(ct.byref(flags)), "flags")
+        assert flags.value == 0                          # sticky until read, then cleared
 
 
 # ------------------------------------------------------------------------------------------------
@@ -219,7 +222,7 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
     ad = load_audiodec(ckpt_root, model, seed, n, max_frames, split16)
     if split16:                                              # the opt-in kernels really are in the programs
         kinds = [ad.decoder._decoder().describe_op(i, 1) for i in range(ad.decoder._decoder().n_ops)]
-        assert any(k.startswith("conv_rl16") for k in kinds), kinds
+        assert any(k.startswith("conv_rl16") or k.startswith("conv_sk16") for k in kinds), kinds
     z, idx, zq, y = run_hip(ad, audio, chunks)
     assert z.shape == g["z"].shape and y.shape == g["y"].shape and idx.shape == g["idx"].shape
     assert np.abs(z - g["z"]).max() < WAVE_TOL

@@ -48,7 +48,7 @@ def run(shape, cfg, B, iters, impl=native.IMPL_MFMA, check=False):
     d.cin_g, d.cout_g, d.groups, d.taps, d.stride, d.dilation, d.hist = cin_g, cout_g, groups, taps, stride, dil, hist
     d.up, d.cout_real, d.in_group_stride, d.res_group_stride = up, cout_real, cin_g, cout_g
     d.act_in, d.act_in_slope, d.act_out = act, 0.1, 0
-    wf = (pack_split16(w.cpu(), groups) if impl == native.IMPL_MFMA_ROWS_SPLIT16 else pack_mfma(w.cpu(), groups)).to(dev)
+    wf = (pack_split16(w.cpu(), groups) if impl in (native.IMPL_SPLIT16, native.IMPL_SPLIT16_ROWS, native.IMPL_SPLIT16_SK) else pack_mfma(w.cpu(), groups)).to(dev)
     d.w, d.w_frag, d.bias = w.data_ptr(), wf.data_ptr(), bias.data_ptr()
     lib.adk_set_conv_cfg(cfg)
     st = native.current_stream(dev)
@@ -84,7 +84,7 @@ if __name__ == "__main__":
     ap.add_argument("--cfg", default="-1")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--impl", type=int, default=native.IMPL_MFMA, help="2 stream-K, 3 rows-in-LDS, 4 split-f16 rows-in-LDS, 0 auto")
+    ap.add_argument("--impl", type=int, default=native.IMPL_MFMA, help="0 auto, 2 stream-K, 3 rows-in-LDS; split-f16: 4 auto, 5 rows-in-LDS, 6 stream-K")
     ap.add_argument("--check", action="store_true", help="compare the output with the f32 stream-K kernel")
     a = ap.parse_args()
     for sh in a.shape.split(","):
