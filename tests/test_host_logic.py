@@ -134,3 +134,29 @@ def test_state_dict_loading_is_strict():
         AutoEncoderStreamGenerator(mode="noncausal")
     _, _, pv = configs.experiment("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean")
     HiFiGANStreamGenerator(**pv).load_state_dict(synth.synth_state_dict("vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean"))
+
+
+def test_split16_packing_layout_and_precision():
+    """pack_split16: [g][m-tile][16-k chunk][hi|lo][lane][8 halfs]; hi + lo/2048 reproduces the f32 weight to 2^-22."""
+    import torch
+    from audiodec_amd import program
+    g = torch.Generator().manual_seed(3)
+    groups, cout_g, ktot = 3, 64, 352                      # K = 11 taps x 32 channels -> padded to 384
+    w = torch.randn(groups * cout_g, ktot, generator=g) * 0.3
+    w[5, 7], w[70, 300] = 3.0e-8, 2.5e-5                   # below the f16 normal range
+    out = program.pack_split16(w, groups)
+    assert out.dtype == torch.float32 and out.numel() == groups * 2 * (384 // 16) * 512
+    h = out.view(torch.float16).reshape(groups, 2, 384 // 16, 2, 2, 32, 8)       # (g, mt, chunk, hi|lo, h, i, j)
+    rec = (h[:, :, :, 0].float() + h[:, :, :, 1].float() / 2048.0)               # (g, mt, chunk, h, i, j)
+    rec = rec.permute(0, 1, 4, 2, 3, 5).reshape(groups, 64, 384)                 # (g, m, k): k = 16*chunk + 8*h + j
+    ref = torch.cat([w.reshape(groups, cout_g, ktot), torch.zeros(groups, cout_g, 32)], 2)
+    err = (rec - ref).abs()
+    assert float(err.max()) <= 2.0 ** -22 * float(w.abs().max())
+    assert float((err / ref.abs().clamp_min(1e-30))[ref.abs() > 1e-3].max()) <= 2.0 ** -21
+    assert float(rec[:, :, ktot:].abs().max()) == 0.0      # zero K tail
+    # values below the f16 normal range are carried by the scaled lo part: absolute error ~1e-11, never flushed to zero
+    assert abs(float(rec[0, 5, 7] - w[5, 7])) < 1e-10 and abs(float(rec[1, 6, 300] - w[70, 300])) < 1e-10
+    with pytest.raises(ValueError):
+        program.pack_split16(torch.full((32, 32), 7.0e4), 1)
+    assert program.split16_eligible(32, 32, 3) and program.split16_eligible(512, 1280, 1)
+    assert not program.split16_eligible(1, 32, 1) and not program.split16_eligible(32, 1, 1)
