@@ -324,9 +324,22 @@ def build_sym_decoder(sd, p, offline=False, split16=False):
     return b
 
 
-def build_hifigan(sd, p, offline=False, split16=False):
+def hifigan_stage_boundary(p, split_at):
+    """(channels, rows per frame) of the tensor between upsample stage split_at-1 and split_at."""
+    ch = p.get("channels", 512)
+    rate = 1
+    for s_ in p["upsample_scales"][:split_at]:
+        rate *= s_
+    return ch // (2 ** split_at), rate
+
+
+def build_hifigan(sd, p, offline=False, split16=False, part=None, split_at=2):
     """HiFiGAN StreamGenerator.decode (HiFiGAN.py:268-296), or with offline=True Generator.forward
-    (:141-161).  ext: [zq, y]."""
+    (:141-161).  ext: [zq, y].
+
+    part = 0 / 1 lowers the path as two programs cut in front of upsample stage `split_at` (ext: [zq, mid] and
+    [mid, y], mid = (B, frames*rate, channels) channel-last): consecutive batches can then be software-pipelined
+    over HIP streams, stage 0 of batch i+1 under stage 1 of batch i (bench.py).  Same ops, same arithmetic."""
     specs = arch.hifigan_convs(p)
     b = Builder(sd, specs, offline, split16)
     act, slope = _act_of(p, "LeakyReLU")
@@ -336,19 +349,30 @@ def build_hifigan(sd, p, offline=False, split16=False):
     addl = p.get("use_additional_convs", True)
     if not addl:
         raise NotImplementedError("use_additional_convs=False is not lowered")
+    n_up = len(p["upsample_scales"])
+    if part is not None and not 0 < split_at < n_up:
+        raise ValueError("split_at must cut between two upsample stages")
+    first = 0 if part in (None, 0) else split_at
+    last = n_up if part in (None, 1) else split_at
     rate = 1
-    rz = b.ring(p["in_channels"], 0, rate)
-    norm = "mean" in sd
-    b.ring_write(rz, 0, sd["mean"] if norm else None, sd["scale"] if norm else None)
-    cur = b.ring(ch, 0, rate)
-    b.conv("input_conv", rz, cur)
+    if first == 0:
+        rz = b.ring(p["in_channels"], 0, rate)
+        norm = "mean" in sd
+        b.ring_write(rz, 0, sd["mean"] if norm else None, sd["scale"] if norm else None)
+        cur = b.ring(ch, 0, rate)
+        b.conv("input_conv", rz, cur)
+    else:
+        c_mid, rate = hifigan_stage_boundary(p, split_at)
+        cur = b.ring(c_mid, 0, rate)
+        b.ring_write(cur, 0)
     c = ch
-    for i, s in enumerate(p["upsample_scales"]):
+    for i in range(first, last):
+        s = p["upsample_scales"][i]
         c = ch // (2 ** (i + 1))
         rate *= s
         x0 = b.ring(c, 0, rate)                                 # block input, un-repeated
         b.conv(f"upsamples.{i}", cur, x0, act, slope)           # upsamples[i].inference(act(c))
-        cur = b.ring(c, 0, rate)
+        cur = b.ring(c, 0, rate, external=1 if (part == 0 and i == last - 1) else -1)
         if multigroup:
             # MultiGroupConv1d.inference (multi_fusion.py:133-141): x.repeat(1, groups, 1) is never
             # materialised -- the first conv and the first residual read the same C channels per group
@@ -373,9 +397,10 @@ def build_hifigan(sd, p, offline=False, split16=False):
                     x = nx
                 outs.append(x)
             b.mean(outs, cur)
-    y = b.ring(p.get("out_channels", 1), 0, rate, external=1)
-    # activation_output1 = nn.LeakyReLU() default slope 0.01 (HiFiGAN.py:116); tanh after (:117)
-    b.conv("output_conv", cur, y, ACT_LEAKY, 0.01, ACT_TANH)
+    if last == n_up:
+        y = b.ring(p.get("out_channels", 1), 0, rate, external=1)
+        # activation_output1 = nn.LeakyReLU() default slope 0.01 (HiFiGAN.py:116); tanh after (:117)
+        b.conv("output_conv", cur, y, ACT_LEAKY, 0.01, ACT_TANH)
     return b
 
 

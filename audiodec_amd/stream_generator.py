@@ -387,11 +387,26 @@ class HiFiGANStreamGenerator(_StreamBase):
         self.norm = p["stats"] is not None
         self.hop = arch.hop_length(p)
         self.dim = p["in_channels"]
+        self.stages = 2 if os.environ.get("ADK_VOCODER_STAGES", "1") == "2" else 1
+        self.split_at = 2
         self._dec = None
+        self._dec_parts = None
 
     def _drop_programs(self):
         self._dec = None
+        self._dec_parts = None
         self._warm = {}
+
+    def set_stages(self, stages=2, split_at=2):
+        """stages=2 lowers the vocoder as two programs cut in front of upsample stage `split_at`; decode() then runs
+        them back to back, decode_stage(i, x) runs one -- callers that process a sequence of batches can put the two
+        stages on different HIP streams (software pipelining over batches, bench.py).  Same ops, same results."""
+        if stages not in (1, 2):
+            raise ValueError("stages must be 1 or 2")
+        if (stages, split_at) != (self.stages, self.split_at):
+            self.stages, self.split_at = stages, split_at
+            self._drop_programs()
+        return self
 
     def _expected_keys(self):
         exp = self._conv_keys(arch.hifigan_convs(self.params))
@@ -401,23 +416,64 @@ class HiFiGANStreamGenerator(_StreamBase):
         return exp
 
     def _decoder(self):
+        """The whole vocoder as one program (stages == 1)."""
+        if self.stages != 1:
+            raise native.NativeError("this generator is lowered in 2 stages: use _decoder_stages()")
         if self._dec is None:
             self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline, self.split16), self.num_streams,
                                            self.max_frames, self._dev())
         return self._dec
 
+    def _decoder_stages(self):
+        if self.stages == 1:
+            return [self._decoder()]
+        if self._dec_parts is None:
+            self._dec_parts = [program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline, self.split16, part, self.split_at),
+                                                  self.num_streams, self.max_frames, self._dev()) for part in (0, 1)]
+        return self._dec_parts
+
     def initial_decoder(self, c):
         self.decode(c)                                         # HiFiGAN.py:264-265
-        self._capture_warm("dec", self._decoder())
+        for i, pr in enumerate(self._decoder_stages()):
+            self._capture_warm("dec" if i == 0 else f"dec{i}", pr)
 
     def _programs(self):
-        return {"dec": self._dec}
+        if self.stages == 1:
+            return {"dec": self._dec}
+        parts = self._dec_parts or [None, None]
+        return {"dec": parts[0], "dec1": parts[1]}
+
+    def decode_stage(self, i, x):
+        """Stage i of a 2-stage lowering: 0: c (B, T, in_channels) -> mid (B, T*rate, channels);
+        1: mid -> (B, 1, T*hop)."""
+        progs = self._decoder_stages()
+        c_mid, r_mid = program.hifigan_stage_boundary(self.params, self.split_at)
+        x = x.to(device=self._dev(), dtype=torch.float32)
+        if i == 0:
+            if x.dim() != 3 or x.shape[2] != self.dim:
+                raise ValueError(f"decode: expected (B, T, {self.dim}), got {tuple(x.shape)}")
+            if x.shape[0] == 1 and self.num_streams > 1:
+                x = x.expand(self.num_streams, -1, -1)
+            if x.shape[0] != self.num_streams:
+                raise ValueError(f"decode: got {x.shape[0]} streams, this object carries {self.num_streams}")
+            T = x.shape[1]
+            if T == 0:
+                return torch.empty(x.shape[0], 0, c_mid, device=x.device)
+            return self._run_chunks(progs[0], x.contiguous(), 1, self.dim, r_mid, c_mid, T)
+        T = x.shape[1] // r_mid
+        if T == 0:
+            return torch.empty(x.shape[0], 1, 0, device=x.device)
+        y = self._run_chunks(progs[1], x.contiguous(), r_mid, c_mid, self.hop, 1, T)
+        return y.reshape(x.shape[0], 1, T * self.hop)
 
     def decode(self, c):
         """c (B, T, in_channels) -> (B, 1, T*hop): norm, input conv, upsample stack, output conv, tanh
         (HiFiGAN.py:268-296)."""
-        return _decode_common(self, self._decoder(), c, self.dim, self.hop)
+        if self.stages == 1:
+            return _decode_common(self, self._decoder(), c, self.dim, self.hop)
+        return self.decode_stage(1, self.decode_stage(0, c))
 
     def reset_buffer(self):
-        if self._dec is not None:
-            self._dec.reset()
+        for pr in self._programs().values():
+            if pr is not None:
+                pr.reset()

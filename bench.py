@@ -63,6 +63,10 @@ class TxRxPipeline:
     def __init__(self, ad, dev):
         self.ad, self.dev = ad, dev
         self.s_tx, self.s_rx = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # a vocoder lowered in two stages (set_stages) gets a third stream: its second half of batch i runs under the
+        # first half of batch i+1 and the encoder of batch i+2
+        self.two = getattr(ad.decoder, "stages", 1) == 2
+        self.s_rx2 = torch.cuda.Stream(dev) if self.two else None
 
     def step(self, x):
         with torch.cuda.stream(self.s_tx):
@@ -74,20 +78,36 @@ class TxRxPipeline:
             self.s_rx.wait_event(ev)
             idx.record_stream(self.s_rx)
             zq = self.ad.rx_encoder.lookup(idx)
-            return self.ad.decoder.decode(zq)
+            if not self.two:
+                return self.ad.decoder.decode(zq)
+            mid = self.ad.decoder.decode_stage(0, zq)
+            ev2 = torch.cuda.Event()
+            ev2.record(self.s_rx)
+        with torch.cuda.stream(self.s_rx2):
+            self.s_rx2.wait_event(ev2)
+            mid.record_stream(self.s_rx2)
+            return self.ad.decoder.decode_stage(1, mid)
 
-    def enter(self):            # both streams start after whatever ran on the current stream
-        cur = torch.cuda.current_stream(self.dev)
-        self.s_tx.wait_stream(cur); self.s_rx.wait_stream(cur)
+    def _all(self):
+        return [s for s in (self.s_tx, self.s_rx, self.s_rx2) if s is not None]
 
-    def exit(self):             # ... and the current stream waits for both
+    def enter(self):            # all streams start after whatever ran on the current stream
         cur = torch.cuda.current_stream(self.dev)
-        cur.wait_stream(self.s_tx); cur.wait_stream(self.s_rx)
+        for s in self._all():
+            s.wait_stream(cur)
+
+    def exit(self):             # ... and the current stream waits for all of them
+        cur = torch.cuda.current_stream(self.dev)
+        for s in self._all():
+            cur.wait_stream(s)
 
 
 def op_profile(ad, xs, streams, n_steps, fps=1):
     """Per-op HIP-event durations (events recorded on the launch stream by the C++ runner)."""
-    progs = {"encoder": ad.tx_encoder._encoder(), "decoder": ad.decoder._decoder()}
+    progs = {"encoder": ad.tx_encoder._encoder()}
+    stages = ad.decoder._decoder_stages() if hasattr(ad.decoder, "_decoder_stages") else [ad.decoder._decoder()]
+    for i, pr in enumerate(stages):
+        progs["decoder" if i == 0 else f"decoder{i}"] = pr
     for p in progs.values():
         p.set_profiling(True)
     acc = {k: np.zeros(p.n_ops) for k, p in progs.items()}
@@ -213,6 +233,8 @@ def main():
                          "profiles/r1_f16_split_probe.txt).  f32: the exact-f32 MFMA kernels everywhere.  The other one is "
                          "timed too and reported under 'other_precision' (single-GPU runs)")
     ap.add_argument("--no-other-precision", action="store_true")
+    ap.add_argument("--stages", type=int, choices=(1, 2), default=2,
+                    help="2: the vocoder is lowered as two programs and its second half runs on a third HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cfg1", action="store_true", help="also time BASELINE config 1 (file round trip) on the host CPU")
     ap.add_argument("--no-op-profile", action="store_true")
@@ -222,6 +244,7 @@ def main():
     import __graft_entry__
     __graft_entry__.build()
     os.environ["ADK_SPLIT16"] = "1" if args.precision == "split16" else "0"    # read by the generators at construction
+    os.environ["ADK_VOCODER_STAGES"] = str(args.stages)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -322,7 +345,8 @@ def main():
                    "streams_per_gpu": B, "streams_total": world * B, "frames_per_step_per_stream": FPS,
                    "sample_rate": 48000, "hop": HOP, "weights": "seeded synthetic (audiodec_amd/synth.py), fp32",
                    "schedule": "serial, one HIP stream" if args.serial else
-                               "transmitter (encode+RVQ) and receiver (lookup+vocoder) on two HIP streams, codes handed over by event"},
+                               ("transmitter (encode+RVQ) and receiver (lookup+vocoder) on two HIP streams, codes handed over by event" if args.stages == 1 else
+                                "3-stage software pipeline over batches on three HIP streams: encode+RVQ | lookup + vocoder stages 0-1 | vocoder stages 2-3 + output, handed over by events")},
         "precision": {"mode": args.precision,
                       "note": "split16: v = hi + lo/2048 with hi = f16(v), lo = f16((v - hi)*2048); sum(a*b) = sum(a_hi*b_hi) + "
                               "(sum(a_hi*b_lo) + sum(a_lo*b_hi))/2048 on v_mfma_f32_32x32x16_f16 with f32 accumulators; measured max "
@@ -363,7 +387,7 @@ def main():
                 out["roofline_convtr"] = roof_ct
                 out["kernels"] = kernels
                 enc_ms = sum(r["ms"] for r in rows if r["prog"] == "encoder")
-                dec_ms = sum(r["ms"] for r in rows if r["prog"] == "decoder")
+                dec_ms = sum(r["ms"] for r in rows if r["prog"].startswith("decoder"))
                 out["latency_ms"]["encoder_kernels_at_batch"] = round(enc_ms, 4)
                 out["latency_ms"]["decoder_kernels_at_batch"] = round(dec_ms, 4)
                 tot_flops = sum(r["flops"] for r in rows)

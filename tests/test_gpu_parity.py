@@ -294,6 +294,41 @@ def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
     assert np.array_equal(one[1], again[1]) and np.array_equal(one[0], again[0]) and np.array_equal(one[3], again[3])
 
 
+def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root):
+    """set_stages(2): the vocoder as two programs (cut in front of upsample stage 2) gives bit-identical output,
+    back to back or with the halves on different HIP streams."""
+    seed, B, hop = 99, 3, 300
+    audio = np.stack([synth.synth_audio(seed, s, 4 * hop) for s in range(B)])
+    ad1 = load_audiodec(ckpt_root, "vctk_v1", seed, B, 2)
+    os.environ["ADK_VOCODER_STAGES"] = "2"
+    try:
+        ad2 = load_audiodec(ckpt_root, "vctk_v1", seed, B, 2)
+    finally:
+        del os.environ["ADK_VOCODER_STAGES"]
+    assert ad1.decoder.stages == 1 and ad2.decoder.stages == 2 and len(ad2.decoder._decoder_stages()) == 2
+    s2 = torch.cuda.Stream(gpu)
+    for f0, f1 in ((0, 1), (1, 3), (3, 4)):
+        x = torch.from_numpy(audio[:, f0 * hop:f1 * hop])[:, None, :].to(gpu)
+        zq = ad1.rx_encoder.lookup(ad1.tx_encoder.quantize(ad1.tx_encoder.encode(x)))
+        y1 = ad1.decoder.decode(zq)
+        if f0 == 1:                                           # halves on two streams, handed over by an event
+            mid = ad2.decoder.decode_stage(0, zq)
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(s2):
+                s2.wait_event(ev)
+                mid.record_stream(s2)
+                y2 = ad2.decoder.decode_stage(1, mid)
+            torch.cuda.current_stream().wait_stream(s2)
+        else:
+            y2 = ad2.decoder.decode(zq)
+        assert y1.shape == y2.shape and torch.equal(y1, y2)
+    ad2.decoder.reset_stream(1)                              # per-stream reset reaches both programs
+    ad1.decoder.reset_stream(1)
+    x = torch.from_numpy(audio[:, :hop])[:, None, :].to(gpu)
+    zq = ad1.rx_encoder.lookup(ad1.tx_encoder.quantize(ad1.tx_encoder.encode(x)))
+    assert torch.equal(ad1.decoder.decode(zq), ad2.decoder.decode(zq))
+
+
 def test_transmitter_receiver_on_two_hip_streams(gpu, ckpt_root):
     """bench.py's schedule: encode+RVQ on one HIP stream, lookup+vocoder on another, codes handed over by an
     event (the reference's two streamer threads).  Concurrent stream-K kernels must not disturb each other."""
