@@ -48,7 +48,8 @@ int launch_hist_replicate(float* ring, int rows, int channels, int cursor, int h
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
 // scratch of the stream-K conv: partial accumulators of cut tiles + publish flags (zeroed once at
 // allocation; flags carry a per-launch epoch, so they are never reset)
-struct Workspace { float* ptr = nullptr; size_t bytes = 0; size_t flags_offset = 0; unsigned epoch = 0; };
+struct Workspace { float* ptr = nullptr; size_t bytes = 0; size_t flags_offset = 0; unsigned epoch = 0;
+                   int workgroups = 0; };   // persistent workgroups per stream-K launch; 0 = the whole chip (256 CUs x 2)
 int launch_conv_mfma(const ConvArgs& a, hipStream_t s, Workspace& ws);   // needs wfrag, cin_g % 32 == 0
 size_t conv_mfma_workspace_bytes(size_t* flags_offset);
 bool conv_rl_supported(const ConvArgs& a);          // rows-in-LDS kernel (stride 1, 32/64 channels per group, time-rich)

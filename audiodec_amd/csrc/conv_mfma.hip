@@ -55,7 +55,6 @@ typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
 constexpr float kSkLoScale = 2048.f, kSkLoInv = 1.f / 2048.f;
 
 constexpr int KC = 64;    // K chunk: two 32-channel half-chunks (each one tap x 32 channels)
-constexpr int LDK = 68;   // padded LDS row stride (floats): conflict-free ds_write_b128 / ds_read_b128
 
 struct SkArgs {
     float* ws;            // partial-tile workspace: [G][256 threads][NJ*16] floats
@@ -158,19 +157,27 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
 // MFMA bursts is exposed, so per-chunk addressing is reduced to buffer loads with one per-thread VGPR
 // offset per staged column (updated by adds) and scalar offsets for the weight stream; columns past
 // N and the zero-padded K tail read out of bounds (= 0) instead of branching.
-template <int WGM, int WGN, int NJ, int ACT, bool SPLIT>
+// KD = K-chunk depth in units of 64 (1: 64-deep, 2: 128-deep).  The split-f16 variant spends so little time in the
+// matrix cores per 64 k that the per-iteration costs (barrier, address update, exposed load latency) dominate: KD = 2
+// puts twice the bytes in flight per iteration and halves the iteration count.
+template <int WGM, int WGN, int NJ, int ACT, bool SPLIT, int KD>
 __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) {
     constexpr int BN = 32 * NJ * WGN;
-    constexpr int RB = BN / 16;                       // staging rounds: 16 columns x 16 quads per round
+    constexpr int KCC = KC * KD;                      // chunk depth
+    constexpr int LDK = KCC + 4;                      // padded LDS row stride (floats); 68 and 132 are both = 4 mod 64
+    constexpr int QPC = 16 * KD;                      // 16-byte pieces per staged column
+    constexpr int CPR = 256 / QPC;                    // columns staged per round
+    constexpr int RB = BN / CPR;                      // staging rounds
     static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(SPLIT || KD == 1, "the exact-f32 variant keeps 64-deep chunks");
     extern __shared__ __attribute__((aligned(16))) float Bs[];   // [2][BN*LDK]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int srow = tid >> 4, quad = tid & 15;       // staged column (mod 16) and 16-byte piece of the 64-float row
-    const int half = quad >> 3;                       // which 32-channel half-chunk this thread stages
+    const int srow = tid / QPC, quad = tid % QPC;     // staged column (mod CPR) and 16-byte piece of the KCC-float row
+    const int half = quad >> 3;                       // which 32-channel sub-chunk (0 .. 2*KD-1) this thread stages
 
     // XCD-contiguous range of work units
     const int r = (int)(blockIdx.x & 7) * (sk.G >> 3) + (int)(blockIdx.x >> 3);
@@ -195,13 +202,13 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     auto stage_tile = [&](int tile, int kc0) {
         sk_tile_coords(tile, sk, s_g, s_mt, s_nt);
         s_tile = tile; s_kc = kc0;
-        const int j = 2 * kc0 + half;                  // index of this thread's 32-deep half-chunk
+        const int j = 2 * KD * kc0 + half;             // index of this thread's 32-deep sub-chunk
         t_tap = j / sk.cpt; t_cblk = j - t_tap * sk.cpt;
         const int n0 = s_nt * BN;
         const unsigned tap_bytes = (unsigned)t_tap * dil_bytes;
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
-            const int n = n0 + srow + 16 * rr;
+            const int n = n0 + srow + CPR * rr;
             const int nn = n < a.n_total ? n : 0;
             const int b = fast_div(nn, a.t_out, sk.inv_t_out), t = nn - b * a.t_out;
             int row = a.in_row0 + t * a.stride;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     auto stage_advance = [&]() {                       // staged chunk -> next chunk (maybe next tile)
         ++s_kc;
         if (s_kc == sk.nchunks) { stage_tile(s_tile + 1, 0); return; }
-        t_cblk += 2;                                   // this thread's half-chunk moves on by two 32-blocks
+        t_cblk += 2 * KD;                              // this thread's sub-chunk moves on by one chunk of 32-blocks
         while (t_cblk >= sk.cpt) {
             t_cblk -= sk.cpt; ++t_tap;
 #pragma unroll
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     };
 
     float4 rb[RB];
-    float4 a_nxt[8];
+    float4 a_nxt[8 * KD];
     auto gload = [&]() {
         const bool k_ok = t_tap < a.taps;              // false on the zero-padded K tail
         const unsigned cb = (unsigned)t_cblk * 128u;
@@ -239,9 +246,9 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
             const unsigned vo = (k_ok && colb[rr] != OOB) ? colb[rr] + rowb[rr] + cb : OOB;
             rb[rr] = buf_load4(rsrc_in, vo, 0);
         }
-        const unsigned sa = s_wbase + (unsigned)s_kc * 8192u;
+        const unsigned sa = s_wbase + (unsigned)s_kc * (8192u * KD);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a_nxt[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
+        for (int q = 0; q < 8 * KD; ++q) a_nxt[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
     };
     bool ovf = false;                                   // SPLIT: an operand beyond the f16 range was staged
     auto lstore = [&](int buf) {
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
             v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
             v.z = act_in_apply<ACT>(v.z, a.slope); v.w = act_in_apply<ACT>(v.w, a.slope);
             if constexpr (SPLIT) {
-                // column row = [64 halfs hi][64 halfs lo][16 B pad]; this thread's 4 floats -> 2 x 8 bytes
+                // column row = [KCC halfs hi][KCC halfs lo][16 B pad]; this thread's 4 floats -> 2 x 8 bytes
                 f16x4s hi, lo;
                 const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -261,11 +268,11 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                     hi[e] = h; lo[e] = (_Float16)((x[e] - (float)h) * kSkLoScale);
                     ovf |= fabsf(x[e]) > 65504.f;
                 }
-                unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + 16 * rr) * LDK) + 8 * quad;
+                unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + CPR * rr) * LDK) + 8 * quad;
                 *reinterpret_cast<f16x4s*>(d) = hi;
-                *reinterpret_cast<f16x4s*>(d + 128) = lo;
+                *reinterpret_cast<f16x4s*>(d + 2 * KCC) = lo;
             } else {
-                *reinterpret_cast<float4*>(Bb + (srow + 16 * rr) * LDK + 4 * quad) = v;
+                *reinterpret_cast<float4*>(Bb + (srow + CPR * rr) * LDK + 4 * quad) = v;
             }
         }
     };
@@ -288,9 +295,9 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     stage_tile(tile, kc);
     gload();
     lstore(0);
-    float4 a_cur[8];
+    float4 a_cur[8 * KD];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a_cur[q] = a_nxt[q];
+    for (int q = 0; q < 8 * KD; ++q) a_cur[q] = a_nxt[q];
     int cur_g = s_g, cur_mt = s_mt, cur_nt = s_nt;
     __syncthreads();
 
@@ -308,14 +315,14 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         if constexpr (SPLIT) {
             const unsigned char* Bh = reinterpret_cast<const unsigned char*>(Bb);     // + 4*lh floats = 16*lh bytes: this lane's 8 halfs
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int st = 0; st < 4 * KD; ++st) {
                 union { float4 f; f16x8s h; } ah, al;
                 ah.f = a_cur[2 * st]; al.f = a_cur[2 * st + 1];
                 f16x8s bh[NJ], bl[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     bh[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st);
-                    bl[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st + 128);
+                    bl[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st + 2 * KCC);
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bh[j], acc[j], 0, 0, 0);
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         __syncthreads();
         cur ^= 1;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a_cur[q] = a_nxt[q];
+        for (int q = 0; q < 8 * KD; ++q) a_cur[q] = a_nxt[q];
         if (++kc == sk.nchunks) { kc = 0; ++tile; }
     }
     if constexpr (SPLIT) { if (ovf) atomicOr(sk.err, 8); }
@@ -464,18 +471,20 @@ const Cfg kCfgs[6] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"
                       {2, 2, 2, "conv_sk<64x128>"}, {1, 4, 1, "conv_sk<32x128>"}, {1, 4, 2, "conv_sk<32x256>"}};
 int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
+int g_fixed_g = 0;         // persistent workgroups per launch when > 0 (ADK_CONV_G / adk_set_conv_workgroups), else 256 * g_occ
 int g_min_units = 2;       // minimum K chunks per workgroup (ADK_CONV_MIN_UNITS; 2 measured best at 256 streams)
 
-template <int WGM, int WGN, int NJ, bool SPLIT>
+template <int WGM, int WGN, int NJ, bool SPLIT, int KD = 1>
 int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN;
-    constexpr size_t lds = 2ull * BN * LDK * sizeof(float);
+    constexpr int KCC = KC * KD;
+    constexpr size_t lds = 2ull * BN * (KCC + 4) * sizeof(float);
     SkArgs sk;
     sk.m_tiles = (a.cout_g + BM - 1) / BM;
     sk.n_tiles = (a.n_total + BN - 1) / BN;
-    sk.nchunks = (a.ktot + KC - 1) / KC;
+    sk.nchunks = (a.ktot + KCC - 1) / KCC;
     sk.cpt = a.cin_g / 32;
-    sk.kgroups = sk.nchunks * (KC / 8);
+    sk.kgroups = (a.ktot + KC - 1) / KC * (KC / 8);   // packing stride: K padded to 64 whatever the chunk depth
     sk.mt32_per_g = (a.cout_g + 31) / 32;
     sk.inv_t_out = 1.0f / (float)a.t_out;
     {
@@ -489,7 +498,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     sk.total = tiles * sk.nchunks;
     // persistent workgroups: 256 CUs x occupancy, but never fewer than g_min_units chunks per workgroup
     // (each one pays a fixed prologue/epilogue, and every cut of a tile costs a partial round trip)
-    long long G = 256LL * g_occ;
+    long long G = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, 256LL * g_occ) : (g_fixed_g > 0 ? g_fixed_g : 256LL * g_occ);
     const long long by_units = (sk.total + g_min_units - 1) / g_min_units;
     if (G > by_units) G = (by_units + 7) / 8 * 8;
     sk.G = (int)G;
@@ -504,18 +513,18 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
-            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT, KD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
     }
     if (a.act_in == ADK_ACT_ELU)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), dim3(sk.G), dim3(256), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_LEAKY)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), dim3(sk.G), dim3(256), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_NONE)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT, KD>), dim3(sk.G), dim3(256), lds, s, a, sk);
     else
         return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
     ADK_HIP_CHECK(hipGetLastError());
@@ -530,6 +539,7 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
     if (g_occ < 0) {
         const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2;
         e = getenv("ADK_CONV_MIN_UNITS"); if (e && atoi(e) >= 1) g_min_units = atoi(e);
+        e = getenv("ADK_CONV_G"); if (e && atoi(e) >= 8 && atoi(e) <= 256 * g_occ) g_fixed_g = atoi(e) / 8 * 8;
     }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);
     if (flags_offset) *flags_offset = part;
@@ -574,7 +584,17 @@ int conv_sk16_pick(const ConvArgs& a) {
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (a.n_total == 0) return ADK_OK;
     (void)conv_mfma_workspace_bytes(nullptr);
-    switch (conv_sk16_pick(a)) {
+    // ADK_SK16_KD=2: 128-deep chunks.  Measured: single launches of the small layers 20-30 % faster (transposed convs
+    // 26.6 -> 18.8 us), single-stream latency 1.09 -> 1.03 ms, but 67.6 KB of LDS per workgroup keeps concurrently
+    // running programs off the CU: 3-stream pipeline 196 k vs 204 k frames/s.  Default 64-deep.
+    static int kd = -1;
+    if (kd < 0) { const char* e = getenv("ADK_SK16_KD"); kd = (e && atoi(e) == 2) ? 2 : 1; }
+    const int pick = conv_sk16_pick(a);
+    if (kd == 2 && a.ktot > 64) {
+        // only the 64x64 tile fits 128-deep chunks without spilling (247 VGPRs; the wider tiles need > 256)
+        if (pick == 2) return launch_cfg<2, 2, 1, true, 2>(a, s, ws);
+    }
+    switch (pick) {
         case 0: return launch_cfg<4, 1, 2, true>(a, s, ws);
         case 1: return launch_cfg<4, 1, 4, true>(a, s, ws);
         case 2: return launch_cfg<2, 2, 1, true>(a, s, ws);

@@ -382,6 +382,13 @@ extern "C" int adk_program_set_cursors(adk_program* p, const int32_t* cursors, i
     return ADK_OK;
 }
 
+extern "C" int adk_program_set_workgroups(adk_program* p, int32_t workgroups) {
+    if (!p) return fail(ADK_ERR_ARG, "program_set_workgroups: null program");
+    if (workgroups < 0 || (workgroups > 0 && workgroups < 8)) return fail(ADK_ERR_SHAPE, "program_set_workgroups: 0 (whole chip) or >= 8");
+    p->ws.workgroups = workgroups / 8 * 8;
+    return ADK_OK;
+}
+
 extern "C" int adk_program_set_profiling(adk_program* p, int32_t enabled) {
     if (!p) return fail(ADK_ERR_ARG, "program_set_profiling: null program");
     p->profiling = enabled != 0;

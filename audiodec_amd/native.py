@@ -72,6 +72,7 @@ SYMBOLS = {
     "adk_program_set_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "adk_program_describe_op": (C.c_int, [_vp, _i32, _i32, C.c_char_p, _i32]),
     "adk_program_set_profiling": (C.c_int, [_vp, _i32]),
+    "adk_program_set_workgroups": (C.c_int, [_vp, _i32]),
     "adk_program_last_op_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
 }
 

@@ -515,6 +515,10 @@ class HipProgram:
             else:
                 v[b, rows] = state[i]
 
+    def set_workgroups(self, workgroups):
+        """Persistent workgroups per stream-K launch (0 = whole chip); see adk_program_set_workgroups."""
+        native.check(self.lib.adk_program_set_workgroups(self.h, int(workgroups)), "adk_program_set_workgroups")
+
     def set_profiling(self, on):
         native.check(self.lib.adk_program_set_profiling(self.h, 1 if on else 0), "adk_program_set_profiling")
 

@@ -53,6 +53,7 @@ class _StreamBase:
         self.num_streams = 1
         self.max_frames = 16
         self.offline = False
+        self.workgroups = 0
         self.split16 = os.environ.get("ADK_SPLIT16", "0") == "1"
         self._warm = {}
 
@@ -85,6 +86,24 @@ class _StreamBase:
             self.split16 = bool(on)
             self._drop_programs()
         return self
+
+    def set_workgroups(self, workgroups):
+        """Share of the chip the stream-K conv launches of this model assume (persistent workgroups, 0 = all):
+        for callers that step several models concurrently on different HIP streams."""
+        self.workgroups = int(workgroups)
+        for pr in self._all_programs():
+            if pr is not None:
+                pr.set_workgroups(self.workgroups)
+        return self
+
+    def _all_programs(self):
+        return list(self._programs().values())
+
+    def _new_program(self, builder):
+        pr = program.HipProgram(builder, self.num_streams, self.max_frames, self._dev())
+        if self.workgroups:
+            pr.set_workgroups(self.workgroups)
+        return pr
 
     def set_offline(self, offline=True):
         """offline=True lowers the NON-streaming Generator.forward used by the file-level drivers
@@ -220,14 +239,12 @@ class AutoEncoderStreamGenerator(_StreamBase):
     # ---- lazily built device state ----
     def _encoder(self):
         if self._enc is None:
-            self._enc = program.HipProgram(program.build_encoder(self._sd, self.params, self.split16), self.num_streams,
-                                           self.max_frames, self._dev())
+            self._enc = self._new_program(program.build_encoder(self._sd, self.params, self.split16))
         return self._enc
 
     def _decoder(self):
         if self._dec is None:
-            self._dec = program.HipProgram(program.build_sym_decoder(self._sd, self.params, self.offline, self.split16), self.num_streams,
-                                           self.max_frames, self._dev())
+            self._dec = self._new_program(program.build_sym_decoder(self._sd, self.params, self.offline, self.split16))
         return self._dec
 
     def _quantizer(self):
@@ -420,16 +437,15 @@ class HiFiGANStreamGenerator(_StreamBase):
         if self.stages != 1:
             raise native.NativeError("this generator is lowered in 2 stages: use _decoder_stages()")
         if self._dec is None:
-            self._dec = program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline, self.split16), self.num_streams,
-                                           self.max_frames, self._dev())
+            self._dec = self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16))
         return self._dec
 
     def _decoder_stages(self):
         if self.stages == 1:
             return [self._decoder()]
         if self._dec_parts is None:
-            self._dec_parts = [program.HipProgram(program.build_hifigan(self._sd, self.params, self.offline, self.split16, part, self.split_at),
-                                                  self.num_streams, self.max_frames, self._dev()) for part in (0, 1)]
+            self._dec_parts = [self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16, part, self.split_at))
+                               for part in (0, 1)]
         return self._dec_parts
 
     def initial_decoder(self, c):

@@ -67,6 +67,12 @@ class TxRxPipeline:
         # first half of batch i+1 and the encoder of batch i+2
         self.two = getattr(ad.decoder, "stages", 1) == 2
         self.s_rx2 = torch.cuda.Stream(dev) if self.two else None
+        # three programs run concurrently: each stream-K launch assumes half the chip's workgroup slots instead of all
+        # of them (measured: 256 persistent workgroups 210 k frames/s, 384: 203 k, 512: 189 k)
+        if self.two and getattr(ad.decoder, "split16", False):     # (the exact-f32 kernels are matrix-core-bound: whole chip is better)
+            wg = int(os.environ.get("ADK_BENCH_WORKGROUPS", "256"))
+            ad.tx_encoder.set_workgroups(wg)
+            ad.decoder.set_workgroups(wg)
 
     def step(self, x):
         with torch.cuda.stream(self.s_tx):

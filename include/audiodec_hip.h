@@ -213,6 +213,10 @@ void adk_program_destroy(adk_program* p);
 int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream);
 /* reset_buffer(): zero all history (AudioDec.py:250-256, HiFiGAN.py:298-305) */
 int adk_program_reset(adk_program* p, void* stream);
+/* How many persistent workgroups the stream-K conv launches of this program use (multiple of 8; 0 = default = the whole
+ * chip, 2 per CU).  A caller that runs several programs CONCURRENTLY on different HIP streams (software pipeline over
+ * batches, bench.py) gives each a share: at 3 concurrent programs 256 measured best (210 k vs 189 k frames/s). */
+int adk_program_set_workgroups(adk_program* p, int32_t workgroups);
 /* ring cursors (n_rings int32), for snapshot / restore of a warmed-up state together with the arena */
 int adk_program_get_cursors(const adk_program* p, int32_t* cursors, int32_t n);
 int adk_program_set_cursors(adk_program* p, const int32_t* cursors, int32_t n);
