@@ -56,6 +56,7 @@ bool conv_rl_supported(const ConvArgs& a);          // rows-in-LDS kernel (strid
 bool conv_rl_preferred(const ConvArgs& a);          // AUTO heuristic: enough (stream, group, tile) workgroups to fill the chip
 int launch_conv_rl(const ConvArgs& a, hipStream_t s);
 bool conv_rl16_supported(const ConvArgs& a);        // split-f16 rows-in-LDS kernel (wfrag = adk_pack_weights_split16 layout)
+bool conv_rl16_preferred(const ConvArgs& a);
 int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
 int conv_sk16_pick(const ConvArgs& a);

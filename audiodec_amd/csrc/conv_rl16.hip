@@ -188,9 +188,10 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                 if (rrow >= a.res_rows) rrow -= a.res_rows;
                 resp = a.res + ((size_t)b * a.res_rows + rrow) * a.res_ch + a.res_choff + g * a.res_gstride;
             }
-            int orow = a.out_cursor + t;
+            int orow = a.out_cursor + t * a.up;              // up > 1: polyphase transposed conv, GEMM row m = phase * cout_real + co
             if (orow >= a.out_rows) orow -= a.out_rows;
-            float* outp = a.out + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + g * a.cout_g;
+            float* outb = a.out + (size_t)b * a.out_rows * a.out_ch + a.out_choff + g * a.cout_g;
+            float* outp = outb + (size_t)orow * a.out_ch;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int ml = mt * 32 + 8 * qd + 4 * lh;
@@ -209,7 +210,14 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                     v.x = act_apply(v.x, a.act_out, 0.f); v.y = act_apply(v.y, a.act_out, 0.f);
                     v.z = act_apply(v.z, a.act_out, 0.f); v.w = act_apply(v.w, a.act_out, 0.f);
                 }
-                if (!(ADK_RL16_DBG & 2) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(outp + ml) = v;
+                float* dst = outp + ml;
+                if (a.up > 1) {
+                    const int ph = ml / a.cout_real;
+                    int r2 = orow + ph;
+                    if (r2 >= a.out_rows) r2 -= a.out_rows;
+                    dst = outb + (size_t)r2 * a.out_ch + (ml - ph * a.cout_real);
+                }
+                if (!(ADK_RL16_DBG & 2) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(dst) = v;
             }
         }
     }
@@ -252,9 +260,10 @@ int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int 
 }
 
 bool conv_rl16_supported(const ConvArgs& a) {
-    if (!a.wfrag || a.stride != 1 || a.up != 1) return false;
+    if (!a.wfrag || a.stride != 1) return false;
     if (a.cin_g != 32 && a.cin_g != 64) return false;
-    if (a.taps != 3 && a.taps != 7 && a.taps != 11) return false;
+    if (a.up != 1 && (a.taps != 2 || a.groups != 1 || a.cout_real % 4 || a.res)) return false;   // transposed convs: 2 taps, polyphase rows
+    if (a.taps != 2 && a.taps != 3 && a.taps != 7 && a.taps != 11) return false;
     if (a.cout_g % 32 != 0) return false;
     if ((a.in_ch % 4) || (a.in_choff % 4) || (a.in_gstride % 4) || (a.out_ch % 4) || (a.out_choff % 4)) return false;
     if (a.res && ((a.res_ch % 4) || (a.res_choff % 4) || (a.res_gstride % 4))) return false;
@@ -262,6 +271,17 @@ bool conv_rl16_supported(const ConvArgs& a) {
     if (a.res && (reinterpret_cast<uintptr_t>(a.res) & 15)) return false;
     if (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15)) return false;
     return true;
+}
+
+// AUTO (ADK_IMPL_SPLIT16): rows-in-LDS when one workgroup per (stream, group, time tile) fills the chip and a stream
+// contributes at least most of an n-tile; else the stream-K variant
+bool conv_rl16_preferred(const ConvArgs& a) {
+    if (!conv_rl16_supported(a) || a.t_out < 24) return false;
+    const int rs = 4 * a.cin_g + 16;
+    const int tt = ((54000 / rs - (a.taps - 1) * a.dilation) / 32) * 32;
+    if (tt < 32) return false;
+    const long long tiles = tt >= a.t_out ? 1 : (a.t_out + tt - 1) / tt;
+    return (long long)a.batch * tiles * a.groups >= 192;
 }
 
 namespace {
@@ -289,6 +309,7 @@ int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
     constexpr int PF = 2;                             // 3 spills at the 168-VGPR budget of 3 workgroups per CU
     auto by_taps = [&](auto act) -> int {
         constexpr int ACT = decltype(act)::value;
+        if (a.taps == 2) return go(conv_rl16_kernel<C, ACT, 2, NW, PF>);
         if (a.taps == 3) return go(conv_rl16_kernel<C, ACT, 3, NW, PF>);
         if (a.taps == 7) return go(conv_rl16_kernel<C, ACT, 7, NW, PF>);
         return go(conv_rl16_kernel<C, ACT, 11, NW, PF>);

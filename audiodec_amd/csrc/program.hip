@@ -83,7 +83,7 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         // split-f16 kernels (w_frag in the adk_pack_weights_split16 layout): rows-in-LDS when it fills the chip, else stream-K
         if (impl == ADK_IMPL_SPLIT16_ROWS && !conv_rl16_supported(a))
             return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
-        if (impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_supported(a) && conv_rl_preferred(a)))
+        if (impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a)))
             return launch_conv_rl16(a, s);
         if (!ok) return fail(ADK_ERR_SHAPE, "conv: split-f16 kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
         int rc = ensure_workspace(ws);
@@ -339,7 +339,7 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         if (rc != ADK_OK) return rc;
         if (o.impl == ADK_IMPL_SPLIT16 || o.impl == ADK_IMPL_SPLIT16_ROWS || o.impl == ADK_IMPL_SPLIT16_SK) {
             if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
-            const bool rows = o.impl == ADK_IMPL_SPLIT16_ROWS || (o.impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_supported(a) && conv_rl_preferred(a));
+            const bool rows = o.impl == ADK_IMPL_SPLIT16_ROWS || (o.impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
             std::string nm = rows ? (a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>") : std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
             snprintf(buf, n, "%s", nm.c_str());
             return ADK_OK;
