@@ -37,6 +37,7 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __
                                                                  const float* __restrict__ enorm, long long* __restrict__ idx,
                                                                  float* __restrict__ zq, int n_rows, int n_q, int dim, int size) {
     __shared__ float r_sh[RB][RVQ_DIM_MAX];
+    __shared__ __attribute__((aligned(16))) float r2t_sh[RVQ_DIM_MAX][RB];   // 2*r, dim-major: one 16-byte broadcast read per d for all RB rows
     __shared__ float q_sh[RB][RVQ_DIM_MAX];
     __shared__ float rn_sh[RB];
     __shared__ float red_v[RB][RVQ_WAVES];
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __
     const int row0 = blockIdx.x * RB;
     for (int e = tid; e < RB * dim; e += RVQ_THREADS) {
         const int rr = e / dim, d = e - rr * dim;
-        r_sh[rr][d] = (row0 + rr < n_rows) ? z[(size_t)(row0 + rr) * dim + d] : 0.f;
+        const float v0 = (row0 + rr < n_rows) ? z[(size_t)(row0 + rr) * dim + d] : 0.f;
+        r_sh[rr][d] = v0;
+        r2t_sh[d][rr] = 2.f * v0;
         q_sh[rr][d] = 0.f;
     }
     __syncthreads();
@@ -80,8 +83,16 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
                     if (d0 + u < dim) {
+                        // the LDS read is a wave-wide broadcast; one b128 per d instead of RB b32 reads keeps the LDS pipe
+                        // (16 waves x 64 d x RB rows per stage) off the critical path
+                        if constexpr (RB == 4) {
+                            const float4 r2 = *reinterpret_cast<const float4*>(&r2t_sh[d0 + u][0]);
+                            acc[0] = fmaf(r2.x, e[u], acc[0]); acc[1] = fmaf(r2.y, e[u], acc[1]);
+                            acc[2] = fmaf(r2.z, e[u], acc[2]); acc[3] = fmaf(r2.w, e[u], acc[3]);
+                        } else {
 #pragma unroll
-                        for (int rr = 0; rr < RB; ++rr) acc[rr] = fmaf(2.f * r_sh[rr][d0 + u], e[u], acc[rr]);
+                            for (int rr = 0; rr < RB; ++rr) acc[rr] = fmaf(r2t_sh[d0 + u][rr], e[u], acc[rr]);
+                        }
                     }
             }
             const float en = EN[c];
@@ -115,7 +126,9 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __
             const float r = r_sh[rr][d];
             const float q = E[(size_t)d * size + best_sh[rr]];
             const float qp = __fadd_rn(r, __fsub_rn(q, r));
-            r_sh[rr][d] = __fsub_rn(r, qp);
+            const float rn = __fsub_rn(r, qp);
+            r_sh[rr][d] = rn;
+            r2t_sh[d][rr] = 2.f * rn;
             q_sh[rr][d] = __fadd_rn(q_sh[rr][d], qp);
         }
         __syncthreads();
