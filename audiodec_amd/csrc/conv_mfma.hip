@@ -47,6 +47,10 @@
 #include "adk_common.h"
 #include <cstdlib>
 
+#ifndef ADK_SK16_DBG
+#define ADK_SK16_DBG 0      // tuning experiments only: 1 = lo part not computed, 2 = no input activation
+#endif
+
 namespace adk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -83,9 +87,12 @@ __device__ __forceinline__ long long sk_u0(int r, const SkArgs& sk) { return (lo
 
 // Epilogue for one wave's 32 x (32*NJ) accumulator block: bias, residual, output activation, store.
 // Lane holds column n = n0w + 32*j + (lane&31) and rows ml0 + 8*qd + 4*(lane>>5) + {0..3}.
-template <int NJ>
-__device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&acc)[NJ], int g, int ml0, int n0w, int lane) {
+// CHECK (split-f16 variant): an operand beyond the f16 range became inf when it was split, so every output it feeds is
+// non-finite -- testing the outputs once here replaces a compare per staged element per tap (5 % of the kernel time).
+template <int NJ, bool CHECK = false>
+__device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&acc)[NJ], int g, int ml0, int n0w, int lane, int* err = nullptr) {
     const int l31 = lane & 31, lh = lane >> 5;
+    bool bad = false;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0w + j * 32 + l31;
@@ -105,6 +112,7 @@ __device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&ac
             if (ml >= a.cout_g) continue;
             const int mg = g * a.cout_g + ml;
             float4 v = make_float4(acc[j][4 * qd], acc[j][4 * qd + 1], acc[j][4 * qd + 2], acc[j][4 * qd + 3]);
+            if (CHECK) bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
             if (a.bias) {
                 const float4 bb = *reinterpret_cast<const float4*>(a.bias + mg);
                 v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -123,6 +131,7 @@ __device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&ac
             *reinterpret_cast<float4*>(outb + (size_t)orow * a.out_ch + ocol) = v;
         }
     }
+    if (CHECK && bad) atomicOr(err, 8);
 }
 
 // tile id -> (group, m-tile, n-tile); M-tile fastest so neighbouring tiles share the X columns and
@@ -250,14 +259,15 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
 #pragma unroll
         for (int q = 0; q < 8 * KD; ++q) a_nxt[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
     };
-    bool ovf = false;                                   // SPLIT: an operand beyond the f16 range was staged
     auto lstore = [&](int buf) {
         float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             float4 v = rb[rr];
-            v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
-            v.z = act_in_apply<ACT>(v.z, a.slope); v.w = act_in_apply<ACT>(v.w, a.slope);
+            if (!(SPLIT && (ADK_SK16_DBG & 2))) {
+                v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
+                v.z = act_in_apply<ACT>(v.z, a.slope); v.w = act_in_apply<ACT>(v.w, a.slope);
+            }
             if constexpr (SPLIT) {
                 // column row = [KCC halfs hi][KCC halfs lo][16 B pad]; this thread's 4 floats -> 2 x 8 bytes
                 f16x4s hi, lo;
@@ -265,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const _Float16 h = (_Float16)x[e];
-                    hi[e] = h; lo[e] = (_Float16)((x[e] - (float)h) * kSkLoScale);
-                    ovf |= fabsf(x[e]) > 65504.f;
+                    hi[e] = h;
+                    lo[e] = (ADK_SK16_DBG & 1) ? (_Float16)0.f : (_Float16)((x[e] - (float)h) * kSkLoScale);
                 }
                 unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + CPR * rr) * LDK) + 8 * quad;
                 *reinterpret_cast<f16x4s*>(d) = hi;
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                             }
                     }
                 }
-                sk_epilogue<NJ>(a, acc, cur_g, ml0, n0w, lane);
+                sk_epilogue<NJ, SPLIT>(a, acc, cur_g, ml0, n0w, lane, sk.err);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -430,7 +440,6 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
         for (int q = 0; q < 8 * KD; ++q) a_cur[q] = a_nxt[q];
         if (++kc == sk.nchunks) { kc = 0; ++tile; }
     }
-    if constexpr (SPLIT) { if (ovf) atomicOr(sk.err, 8); }
 }
 
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]

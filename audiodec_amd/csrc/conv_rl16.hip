@@ -9,8 +9,8 @@
 // (2^-22 relative) and the 2^-22 representation error of each operand -- measured on gfx950 against fp64
 // (tools/mfma_f16_probe.hip, profiles/r1_f16_split_probe.txt): max |err| / sum|a b| = 8e-8 for K = 352..2816,
 // BELOW the 2e-7 of the f32 MFMA chain (which rounds after every product), at 3/16 of its matrix-core time.
-// f16 subnormal inputs are honoured by the instruction (same probe), |v| > 65504 would overflow hi and raises
-// device flag bit 3 (adk_debug_flags).  Weights come pre-split in fragment order (adk_pack_weights_split16).
+// f16 subnormal inputs are honoured by the instruction (same probe); |v| > 65504 overflows hi to inf, which makes every
+// output it feeds non-finite -- the epilogue tests its outputs and raises device flag bit 3 (adk_debug_flags).  Weights come pre-split in fragment order (adk_pack_weights_split16).
 #include "adk_common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -44,14 +44,13 @@ __device__ __forceinline__ float rl16_act(float x, float slope) {
     return x;
 }
 
-__device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo, bool& bad) {
+__device__ __forceinline__ void split8(const float4& u, const float4& v, f16x8& hi, f16x8& lo) {
     const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const _Float16 h = (_Float16)x[j];
         hi[j] = h;
         lo[j] = (_Float16)((x[j] - (float)h) * kLoScale);
-        bad |= fabsf(x[j]) > 65504.f;
     }
 }
 
@@ -88,7 +87,6 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
         const int rows_all = rl.span + 32 * n_tiles;
         constexpr int C8 = C / 8;
         const int items = rows_all * C8;
-        bool bad = false;
         for (int i0 = tid; i0 < items; i0 += 2 * NT) {          // two items per pass: both loads in flight together
             float4 u[2], v[2];
             int rr[2], c8[2];
@@ -113,13 +111,12 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                 vv.x = rl16_act<ACT>(vv.x, a.slope); vv.y = rl16_act<ACT>(vv.y, a.slope);
                 vv.z = rl16_act<ACT>(vv.z, a.slope); vv.w = rl16_act<ACT>(vv.w, a.slope);
                 f16x8 hi, lo;
-                split8(uu, vv, hi, lo, bad);
+                split8(uu, vv, hi, lo);
                 unsigned char* d = xs + rr[k] * RS + 16 * c8[k];
                 *reinterpret_cast<f16x8*>(d) = hi;
                 *reinterpret_cast<f16x8*>(d + 2 * C) = lo;
             }
         }
-        if (bad) atomicOr(rl.err, 8);
     }
     __syncthreads();
 
@@ -174,7 +171,9 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
             }
         }
-        // ---- epilogue: acc0 + acc1/2048, bias, residual, output activation, store ----
+        // ---- epilogue: acc0 + acc1/2048, bias, residual, output activation, store.  An operand beyond the f16 range was
+        // split into inf parts, so every output it feeds is non-finite: checked here, once per output ----
+        bool bad = false;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (j == 1 && !two) break;
@@ -198,6 +197,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                 if (ml >= a.cout_g) continue;
                 float4 v = make_float4(fmaf(ac[4 * qd], kLoInv, am[4 * qd]), fmaf(ac[4 * qd + 1], kLoInv, am[4 * qd + 1]),
                                        fmaf(ac[4 * qd + 2], kLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kLoInv, am[4 * qd + 3]));
+                bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
                 if (a.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(a.bias + g * a.cout_g + ml);
                     v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                 if (!(ADK_RL16_DBG & 2) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(dst) = v;
             }
         }
+        if (bad) atomicOr(rl.err, 8);
     }
 }
 

@@ -44,7 +44,7 @@ enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K imp
        /* Opt-in split-precision kernels: every f32 operand is carried as f16 hi + f16 lo/2048 and a product sum is
           formed from three f16 MFMAs (hi*hi, hi*lo, lo*hi) with f32 accumulation -- measured error vs fp64 is
           below that of the f32 MFMA chain (profiles/r1_f16_split_probe.txt).  w_frag must then hold the
-          adk_pack_weights_split16 layout.  |operand| > 65504 raises device flag bit 3.
+          adk_pack_weights_split16 layout.  |operand| > 65504 (-> non-finite outputs) raises device flag bit 3.
           SPLIT16 picks between the rows-in-LDS and the stream-K variant like AUTO does; the other two force one. */
        ADK_IMPL_SPLIT16 = 4, ADK_IMPL_SPLIT16_ROWS = 5, ADK_IMPL_SPLIT16_SK = 6 };
 
@@ -53,8 +53,8 @@ int adk_abi_version(void);
 /* sticky device-side flags since the last call (bit 0: adk_rvq_lookup saw an out-of-range index,
  * where F.embedding would raise; bit 1: a stream-K conv workgroup gave up waiting for another workgroup's
  * partial tile -- results of that launch are invalid; bit 2: adk_codes_pack saw an index that
- * is not a code of its stage; bit 3: a split-f16 kernel met an operand beyond the f16 range (|v| > 65504) --
- * results of that launch are invalid); reading synchronises the device
+ * is not a code of its stage; bit 3: a split-f16 kernel produced a non-finite output -- an operand beyond the f16 range (|v| > 65504) or a
+ * non-finite input; results of that launch are invalid); reading synchronises the device
  * and clears them */
 int adk_debug_flags(int32_t* out);
 /* tuning hook: force the MFMA conv tile config (0..5), -1 = heuristic (also env ADK_CONV_CFG) */
