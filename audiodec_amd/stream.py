@@ -1,12 +1,16 @@
-"""Codec loader base and real-time streamer (mirrors /root/reference/bin/stream.py).
+"""Codec loader base and live single-stream streamer for the HIP path.
 
-``AudioCodec`` (bin/stream.py:23-77) is the load path: read ``config.yml`` next to the checkpoint,
-build the model, warm it up.  ``AudioCodecStreamer`` (bin/stream.py:80-366) is the device-agnostic
-queue/thread runtime around ``_encode`` / ``_decode``; it is not on the accelerated path, so it is
-kept behaviourally identical (same queues, latency bookkeeping, frame-drop rule, statistics
-printout); WAV dumps go through ``scipy.io.wavfile`` because torchaudio is not a dependency here.
+Public surface = what the reference's demos touch (/root/reference/bin/stream.py): ``AudioCodec``
+(``load_transmitter`` / ``load_receiver``, :23-77) and ``AudioCodecStreamer`` (constructor keywords,
+``enable_filedump``, ``run``, the ``_encode`` / ``_decode`` hooks, :80-366).  The runtime behind it is organised
+differently from the reference: a generic ``_Stage`` worker thread per model half, a ``_LatencyLedger`` that owns the
+time stamps and the frame-drop rule, and ``_WavSink`` objects for the optional dumps.  Behaviour kept: input gain,
+silence when no decoded block is ready, and the rule that a block whose end-to-end latency exceeds ``max_latency``
+flushes everything in flight and counts the flushed blocks as drops (bin/stream.py:259-266).  None of this is on the
+accelerated path; WAV dumps use ``scipy.io.wavfile``.
 """
 import abc
+import collections
 import os
 import queue
 import threading
@@ -65,15 +69,78 @@ class AudioCodec(abc.ABC):
         print("Load decoder: %s" % (decoder_checkpoint))
 
 
-def _save_wav(path, audio, sample_rate):
-    """audio: (channels, samples) float tensor in [-1, 1] -> 16-bit PCM WAV."""
-    from scipy.io import wavfile
-    data = (audio.transpose(1, 0).numpy() * 32767.0).round().astype(np.int16)
-    wavfile.write(path, int(sample_rate), data)
+class _WavSink:
+    """Collects (channels, samples) blocks and writes one clipped 16-bit PCM file when closed."""
+
+    def __init__(self, path, sample_rate):
+        self.path = path if path.endswith(".wav") else path + ".wav"
+        self.sample_rate = int(sample_rate)
+        self.blocks = []
+
+    def push(self, block):
+        self.blocks.append(block)
+
+    def close(self):
+        if not self.blocks:
+            return
+        from scipy.io import wavfile
+        audio = torch.cat(self.blocks, dim=-1).clamp(-1.0, 1.0)
+        pcm = (audio.transpose(1, 0).numpy() * 32767.0).round().astype(np.int16)
+        wavfile.write(self.path, self.sample_rate, pcm)
+
+
+class _LatencyLedger:
+    """Time stamps of the blocks in flight, completed latencies, and the drop count."""
+
+    def __init__(self, limit_s):
+        self.limit_s = limit_s
+        self.in_flight = collections.deque()
+        self.done = []
+        self.drops = 0
+        self.blocks = 0
+
+    def submitted(self):
+        self.in_flight.append(time.time())
+
+    def completed(self):
+        """Latency of the oldest block in flight; True when it breaks the limit."""
+        lat = time.time() - self.in_flight.popleft()
+        self.done.append(lat)
+        return lat > self.limit_s
+
+    def flush(self):
+        self.drops += len(self.in_flight)
+        self.in_flight.clear()
+
+
+class _Stage(threading.Thread):
+    """One model half as a daemon worker: inbox -> fn(x on device) -> outbox, with per-block wall times."""
+
+    def __init__(self, name, fn, device, inbox, outbox):
+        super().__init__(name=name, daemon=True)
+        self.fn, self.device, self.inbox, self.outbox = fn, device, inbox, outbox
+        self.times = []
+
+    def run(self):
+        while threading.main_thread().is_alive():
+            try:
+                x = self.inbox.get(timeout=1)
+            except queue.Empty:
+                continue
+            t0 = time.time()
+            with torch.no_grad():
+                y = self.fn(x.to(self.device))
+            self.times.append(time.time() - t0)
+            self.outbox.put(y)
+
+
+def _ms(values):
+    a = np.asarray(values, dtype=np.float64) * 1e3
+    return (float(a.mean()), float(a.std())) if a.size else (float("nan"), float("nan"))
 
 
 class AudioCodecStreamer(abc.ABC):
-    """Microphone -> encoder thread -> decoder thread -> speaker (bin/stream.py:80-366)."""
+    """Sound card -> encoder stage -> decoder stage -> sound card, one block of ``frame_size`` samples per callback."""
 
     def __init__(
         self,
@@ -91,35 +158,23 @@ class AudioCodecStreamer(abc.ABC):
         decoder=None,
         rx_device: str = "cpu",
     ):
-        self.input_device = input_device
-        self.output_device = output_device
-        self.input_channels = input_channels
-        self.output_channels = output_channels
-        self.frame_size = frame_size
-        self.sample_rate = sample_rate
-        self.gain = gain
-        self.max_latency = max_latency
-        self.tx_encoder = tx_encoder
-        self.tx_device = tx_device
+        self.input_device, self.output_device = input_device, output_device
+        self.input_channels, self.output_channels = input_channels, output_channels
+        self.frame_size, self.sample_rate = frame_size, sample_rate
+        self.gain, self.max_latency = gain, max_latency
+        self.tx_encoder, self.tx_device = tx_encoder, tx_device
+        self.rx_encoder, self.decoder, self.rx_device = rx_encoder, decoder, rx_device
         print(f"Encoder device: {tx_device}")
-        self.rx_encoder = rx_encoder
-        self.decoder = decoder
-        self.rx_device = rx_device
         print(f"Decoder device: {rx_device}")
-        self.encoder_queue = queue.Queue()
-        self.decoder_queue = queue.Queue()
-        self.output_queue = queue.Queue()
-        self.input_dump = []
-        self.output_dump = []
-        self.input_dump_filename = None
-        self.output_dump_filename = None
-        self.frame_drops = 0
-        self.n_frames = 0
-        self.encoder_times = []
-        self.decoder_times = []
-        self.latency_queue = queue.Queue()
-        self.latencies = []
+        self._to_tx, self._to_rx, self._to_out = queue.Queue(), queue.Queue(), queue.Queue()
+        self._ledger = _LatencyLedger(max_latency)
+        self._sinks = {"in": None, "out": None}
+        have_tx = tx_encoder is not None
+        have_rx = rx_encoder is not None and decoder is not None
+        self._tx = _Stage("adk-tx", self._encode if have_tx else (lambda x: x), tx_device, self._to_tx, self._to_rx)
+        self._rx = _Stage("adk-rx", self._decode if have_rx else (lambda x: x), rx_device, self._to_rx, self._to_out)
 
+    # ---- model hooks supplied by the subclass (utils/audiodec.py:100-106) ----
     @abc.abstractmethod
     def _encode(self, x):
         pass
@@ -128,121 +183,81 @@ class AudioCodecStreamer(abc.ABC):
     def _decode(self, x):
         pass
 
-    def _run_encoder(self):
-        while threading.main_thread().is_alive():
-            try:
-                x = self.encoder_queue.get(timeout=1)
-            except queue.Empty:
-                continue
-            start = time.time()
-            x = x.to(self.tx_device)
-            with torch.no_grad():
-                if self.tx_encoder is not None:
-                    x = self._encode(x)
-            self.encoder_times.append(time.time() - start)
-            self.decoder_queue.put(x)
+    # ---- statistics the callers may read ----
+    @property
+    def frame_drops(self):
+        return self._ledger.drops
 
-    def _run_decoder(self):
-        while threading.main_thread().is_alive():
-            try:
-                x = self.decoder_queue.get(timeout=1)
-            except queue.Empty:
-                continue
-            start = time.time()
-            x = x.to(self.rx_device)
-            with torch.no_grad():
-                if (self.rx_encoder is not None) and (self.decoder is not None):
-                    x = self._decode(x)
-            self.decoder_times.append(time.time() - start)
-            self.output_queue.put(x)
+    @property
+    def n_frames(self):
+        return self._ledger.blocks
 
-    def _process(self, data):
-        data = data * self.gain
-        input_data = torch.from_numpy(data).transpose(1, 0).contiguous()  # channels x frame_size
-        if self.input_dump_filename is not None:
-            self.input_dump.append(input_data)
-        input_data = input_data.unsqueeze(0)
-        self.encoder_queue.put(input_data)
-        self.latency_queue.put(time.time())
+    def tick(self, block):
+        """Body of the audio callback: block (frame_size, in_channels) float32 in, (frame_size, out_channels) out."""
+        x = torch.from_numpy(block * self.gain).transpose(1, 0).contiguous()          # channels x frame_size
+        if self._sinks["in"] is not None:
+            self._sinks["in"].push(x)
+        self._to_tx.put(x.unsqueeze(0))
+        self._ledger.submitted()
         try:
-            output_data = self.output_queue.get_nowait()
-            latency = time.time() - self.latency_queue.get_nowait()
-            self.latencies.append(latency)
-            # clear queues if latency gets too high; this leads to frame drops (bin/stream.py:259-266)
-            if latency > self.max_latency:
-                self.encoder_queue.queue.clear()
-                self.decoder_queue.queue.clear()
-                self.output_queue.queue.clear()
-                while not self.latency_queue.empty():
-                    self.frame_drops += 1
-                    self.latency_queue.get_nowait()
+            y = self._to_out.get_nowait()
         except queue.Empty:
-            output_data = torch.zeros(1, self.output_channels, self.frame_size)
-        output_data = output_data.squeeze(0).detach().cpu()
-        self.n_frames += 1
-        if self.output_dump_filename is not None:
-            self.output_dump.append(output_data)
-        return output_data.transpose(1, 0).contiguous().numpy()
-
-    def _callback(self, indata, outdata, frames, _time, status):
-        if status:
-            print(status)
-        outdata[:] = self._process(indata)
-
-    def _exit(self):
-        if self.input_dump_filename is not None:
-            audio = torch.clamp(torch.cat(self.input_dump, dim=-1), min=-1, max=1)
-            _save_wav(self.input_dump_filename, audio, self.sample_rate)
-        if self.output_dump_filename is not None:
-            audio = torch.clamp(torch.cat(self.output_dump, dim=-1), min=-1, max=1)
-            _save_wav(self.output_dump_filename, audio, self.sample_rate)
-        with threading.Lock():
-            encoder_mean = np.mean(np.array(self.encoder_times) * 1000.0)
-            encoder_std = np.std(np.array(self.encoder_times) * 1000.0)
-            decoder_mean = np.mean(np.array(self.decoder_times) * 1000.0)
-            decoder_std = np.std(np.array(self.decoder_times) * 1000.0)
-            latency_mean = np.mean(np.array(self.latencies) * 1000.0)
-            latency_std = np.std(np.array(self.latencies) * 1000.0)
-        frame_drops_ratio = self.frame_drops / max(self.n_frames, 1)
-        print("#" * 80)
-        print(f"encoder processing time (ms):      {encoder_mean:.2f} +- {encoder_std:.2f}")
-        print(f"decoder processing time (ms):      {decoder_mean:.2f} +- {decoder_std:.2f}")
-        print(f"system latency (ms):               {latency_mean:.2f} +- {latency_std:.2f}")
-        print(f"frame drops:                       {self.frame_drops} ({frame_drops_ratio * 100:.2f}%)")
-        print("#" * 80)
+            y = torch.zeros(1, self.output_channels, self.frame_size)                  # nothing decoded yet: silence
+        else:
+            if self._ledger.completed():                                               # too late: start over
+                for q in (self._to_tx, self._to_rx, self._to_out):
+                    with q.mutex:
+                        q.queue.clear()
+                self._ledger.flush()
+        y = y.squeeze(0).detach().cpu()
+        self._ledger.blocks += 1
+        if self._sinks["out"] is not None:
+            self._sinks["out"].push(y)
+        return y.transpose(1, 0).contiguous().numpy()
 
     def enable_filedump(self, input_stream_file: str = None, output_stream_file: str = None):
         if input_stream_file is None and output_stream_file is None:
             raise Exception("At least one of input_stream_file and output_stream_file must be specified.")
         if input_stream_file is not None:
-            if not input_stream_file[-4:] == ".wav":
-                input_stream_file += ".wav"
-            self.input_dump_filename = input_stream_file
+            self._sinks["in"] = _WavSink(input_stream_file, self.sample_rate)
         if output_stream_file is not None:
-            if not output_stream_file[-4:] == ".wav":
-                output_stream_file += ".wav"
-            self.output_dump_filename = output_stream_file
+            self._sinks["out"] = _WavSink(output_stream_file, self.sample_rate)
+
+    def report(self):
+        """Write the dumps and print the run statistics."""
+        for sink in self._sinks.values():
+            if sink is not None:
+                sink.close()
+        rows = (("encoder processing time (ms)", _ms(self._tx.times)), ("decoder processing time (ms)", _ms(self._rx.times)),
+                ("system latency (ms)", _ms(self._ledger.done)))
+        bar = "#" * 80
+        print(bar)
+        for label, (mean, std) in rows:
+            print(f"{label + ':':35s}{mean:.2f} +- {std:.2f}")
+        share = 100.0 * self._ledger.drops / max(self._ledger.blocks, 1)
+        print(f"{'frame drops:':35s}{self._ledger.drops} ({share:.2f}%)")
+        print(bar)
 
     def run(self, latency):
-        encoder_thread = threading.Thread(target=self._run_encoder, daemon=True)
-        encoder_thread.start()
-        decoder_thread = threading.Thread(target=self._run_decoder, daemon=True)
-        decoder_thread.start()
+        """Open the duplex sound-card stream and pump blocks until Return is pressed (needs ``sounddevice``)."""
+        self._tx.start()
+        self._rx.start()
+
+        def callback(indata, outdata, frames, _time, status):
+            if status:
+                print(status)
+            outdata[:] = self.tick(indata)
+
         try:
             import sounddevice as sd
-            with sd.Stream(
-                device=(self.input_device, self.output_device),
-                samplerate=self.sample_rate,
-                blocksize=self.frame_size,
-                dtype=np.float32,
-                latency=latency,
-                channels=(self.input_channels, self.output_channels),
-                callback=self._callback,
-            ):
+            stream = sd.Stream(device=(self.input_device, self.output_device), samplerate=self.sample_rate,
+                               blocksize=self.frame_size, dtype=np.float32, latency=latency,
+                               channels=(self.input_channels, self.output_channels), callback=callback)
+            with stream:
                 print("### starting stream [press Return to quit] ###")
                 input()
-                self._exit()
+            self.report()
         except KeyboardInterrupt:
-            self._exit()
-        except Exception as e:
+            self.report()
+        except Exception as e:                                   # the reference prints and swallows (bin/stream.py:365-366)
             print(type(e).__name__ + ": " + str(e))

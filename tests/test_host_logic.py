@@ -160,3 +160,45 @@ def test_split16_packing_layout_and_precision():
         program.pack_split16(torch.full((32, 32), 7.0e4), 1)
     assert program.split16_eligible(32, 32, 3) and program.split16_eligible(512, 1280, 1)
     assert not program.split16_eligible(1, 32, 1) and not program.split16_eligible(32, 1, 1)
+
+
+def test_streamer_runtime_tick_latency_rule_and_dumps(tmp_path):
+    """AudioCodecStreamer without a sound card: the callback body, the two stage threads, the frame-drop rule
+    (bin/stream.py:259-266) and the WAV dumps."""
+    import time
+    from audiodec_amd import stream
+
+    class Echo(stream.AudioCodecStreamer):
+        def _encode(self, x):
+            return x * 2.0
+
+        def _decode(self, x):
+            return x + 1.0
+
+    s = Echo(0, 0, frame_size=8, sample_rate=8000, gain=0.5, max_latency=10.0, tx_encoder=object(), rx_encoder=object(),
+             decoder=object())
+    with pytest.raises(Exception):
+        s.enable_filedump()
+    s.enable_filedump(str(tmp_path / "in"), str(tmp_path / "out.wav"))
+    s._tx.start(); s._rx.start()
+    blk = np.full((8, 1), 0.25, np.float32)
+    out0 = s.tick(blk)
+    assert out0.shape == (8, 1) and np.all(out0 == 0.0)          # nothing decoded yet: silence
+    deadline = time.time() + 5.0
+    while s._to_out.empty() and time.time() < deadline:
+        time.sleep(0.01)
+    out1 = s.tick(blk)
+    assert np.allclose(out1, 0.25 * 0.5 * 2.0 + 1.0)             # gain -> _encode -> _decode
+    assert s.n_frames == 2 and s.frame_drops == 0
+    # a block that comes back later than max_latency flushes everything in flight and counts the flushed blocks
+    s._ledger.limit_s = 0.0
+    while s._to_out.empty() and time.time() < deadline:
+        time.sleep(0.01)
+    s.tick(blk)
+    assert s.frame_drops >= 1 and s._to_tx.empty() and s._to_rx.empty() and s._to_out.empty()
+    s.report()
+    from scipy.io import wavfile
+    fs, a = wavfile.read(str(tmp_path / "in.wav"))                # ".wav" appended
+    assert fs == 8000 and a.shape[0] == 24
+    fs, b = wavfile.read(str(tmp_path / "out.wav"))
+    assert b.shape[0] == 24 and b.max() == 32767                 # 1.125 clipped to full scale

@@ -225,3 +225,33 @@ def test_codectest_and_codecstatistic_end_to_end(gpu, golden_dir, tmp_path):
     ref = np.stack([sc.mean_, sc.scale_]).astype(np.float32)
     assert stats.shape == (2, 64) and np.abs(stats - ref).max() <= 1e-5
     assert np.array_equal(np.load(os.path.join(root, "stats_out", "s.npy")), stats)
+
+
+@pytest.mark.gpu
+def test_demofile_round_trip_cli(gpu, tmp_path):
+    """demoFile.py as a command: 2-channel WAV in, same-length WAV out, equal to the oracle's round trip of the
+    PCM-16 input (every channel is one stream)."""
+    import subprocess
+    import sys
+    from audiodec_amd import offline
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = str(tmp_path)
+    seed = 1337
+    synth.write_model(root, "libritts_sym", seed)
+    x = np.stack([synth.synth_audio(seed, 7 + c, 3100) for c in range(2)], 1)          # (T, 2), ragged length
+    offline.write_wav_pcm16(os.path.join(root, "in.wav"), x, 24000)
+    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(repo, "demoFile.py"), "--model", "libritts_sym", "-i", "in.wav", "-o", "out.wav"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    y = offline.read_wav(os.path.join(root, "out.wav"))
+    assert y.shape == (3100, 2)
+    # oracle: the streaming one-shot path of demoFile.py:58-61 from the warmed-up state, per channel
+    from test_oracle_golden import build_oracle
+    xin = offline.read_wav(os.path.join(root, "in.wav"))
+    for c in range(2):
+        tx, rx, dec = build_oracle("libritts_sym", 1, seed)
+        xt = torch.tensor(xin[:, c], dtype=torch.float)[None, None, :]
+        with torch.no_grad():
+            yo = dec.decode(rx.lookup(tx.quantize(tx.encode(xt))))[0, 0, :3100].numpy()
+        assert np.abs(y[:, c] - yo).max() <= WAVE_TOL + 2.0 / 32767
