@@ -234,14 +234,15 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
     assert np.abs(y - g["y"]).max() < WAVE_TOL, f"max|dy| = {np.abs(y - g['y']).max():.3e}"
 
 
-@pytest.mark.parametrize("model,B,frames", [("vctk_v1", 16, [1, 1, 2, 1]), ("vctk_sym", 33, [1, 3])])
-def test_batched_streams_match_oracle(gpu, ckpt_root, model, B, frames):
+@pytest.mark.parametrize("model,B,frames,split16", [("vctk_v1", 16, [1, 1, 2, 1], False), ("vctk_sym", 33, [1, 3], False),
+                                                    ("vctk_v1", 16, [1, 1, 2, 1], True), ("vctk_sym", 33, [1, 3], True)])
+def test_batched_streams_match_oracle(gpu, ckpt_root, model, B, frames, split16):
     """B streams in one object == the B-stream oracle (B independent reference instances)."""
     seed = 4242
     hop = 300
     chunks = [f * hop for f in frames]
     audio = np.stack([synth.synth_audio(seed, 100 + s, sum(chunks)) for s in range(B)])
-    ad = load_audiodec(ckpt_root, model, seed, B, 2)
+    ad = load_audiodec(ckpt_root, model, seed, B, 2, split16)
     z, idx, zq, y = run_hip(ad, audio, chunks)
     tx, rx, dec = build_oracle(model, B, seed)
     oz, oi, om, oy = [], [], [], []
@@ -297,15 +298,17 @@ def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
     assert np.array_equal(one[1], again[1]) and np.array_equal(one[0], again[0]) and np.array_equal(one[3], again[3])
 
 
-def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root):
+@pytest.mark.parametrize("model,split16", [("vctk_v1", False), ("vctk_v1", True), ("vctk_v0", False)])
+def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16):
     """set_stages(2): the vocoder as two programs (cut in front of upsample stage 2) gives bit-identical output,
-    back to back or with the halves on different HIP streams."""
+    back to back or with the halves on different HIP streams (v1: grouped convs + 1x1; v0: three residual blocks
+    averaged into the hand-over buffer)."""
     seed, B, hop = 99, 3, 300
     audio = np.stack([synth.synth_audio(seed, s, 4 * hop) for s in range(B)])
-    ad1 = load_audiodec(ckpt_root, "vctk_v1", seed, B, 2)
+    ad1 = load_audiodec(ckpt_root, model, seed, B, 2, split16)
     os.environ["ADK_VOCODER_STAGES"] = "2"
     try:
-        ad2 = load_audiodec(ckpt_root, "vctk_v1", seed, B, 2)
+        ad2 = load_audiodec(ckpt_root, model, seed, B, 2, split16)
     finally:
         del os.environ["ADK_VOCODER_STAGES"]
     assert ad1.decoder.stages == 1 and ad2.decoder.stages == 2 and len(ad2.decoder._decoder_stages()) == 2

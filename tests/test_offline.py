@@ -140,9 +140,11 @@ def gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split16", [False, True], ids=["f32", "split16"])
 @pytest.mark.parametrize("name", OFFLINE)
-def test_testmain_matches_reference_forward(gpu, golden_dir, tmp_path, name):
+def test_testmain_matches_reference_forward(gpu, golden_dir, tmp_path, monkeypatch, name, split16):
     from audiodec_amd import offline
+    monkeypatch.setenv("ADK_SPLIT16", "1" if split16 else "0")
     g = _load(golden_dir, name)
     model, seed = str(g["model"]), int(g["seed"])
     root = str(tmp_path)
@@ -155,6 +157,7 @@ def test_testmain_matches_reference_forward(gpu, golden_dir, tmp_path, name):
         tm.load_decoder()
     finally:
         os.chdir(cwd)
+    assert tm.encoder.split16 == split16 and tm.decoder.split16 == split16
     for rep in range(2):                                         # second pass: per-utterance reset really resets
         for n, L in enumerate(g["lengths"]):
             zq = tm.encode(_audio(seed, n, int(L)))
