@@ -264,7 +264,7 @@ bool conv_rl16_supported(const ConvArgs& a) {
     if (!a.wfrag || a.stride != 1) return false;
     if (a.cin_g != 32 && a.cin_g != 64) return false;
     if (a.up != 1 && (a.taps != 2 || a.groups != 1 || a.cout_real % 4 || a.res)) return false;   // transposed convs: 2 taps, polyphase rows
-    if (a.taps != 2 && a.taps != 3 && a.taps != 7 && a.taps != 11) return false;
+    if (a.taps != 1 && a.taps != 2 && a.taps != 3 && a.taps != 7 && a.taps != 11) return false;   // tap loop unrolled at compile time
     if (a.cout_g % 32 != 0) return false;
     if ((a.in_ch % 4) || (a.in_choff % 4) || (a.in_gstride % 4) || (a.out_ch % 4) || (a.out_choff % 4)) return false;
     if (a.res && ((a.res_ch % 4) || (a.res_choff % 4) || (a.res_gstride % 4))) return false;
@@ -310,6 +310,7 @@ int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
     constexpr int PF = 2;                             // 3 spills at the 168-VGPR budget of 3 workgroups per CU
     auto by_taps = [&](auto act) -> int {
         constexpr int ACT = decltype(act)::value;
+        if (a.taps == 1) return go(conv_rl16_kernel<C, ACT, 1, NW, PF>);
         if (a.taps == 2) return go(conv_rl16_kernel<C, ACT, 2, NW, PF>);
         if (a.taps == 3) return go(conv_rl16_kernel<C, ACT, 3, NW, PF>);
         if (a.taps == 7) return go(conv_rl16_kernel<C, ACT, 7, NW, PF>);
