@@ -334,12 +334,18 @@ def hifigan_stage_boundary(p, split_at):
 
 
 def build_hifigan(sd, p, offline=False, split16=False, part=None, split_at=2):
+    """See below; `split_at` may be an int (one cut) or a sorted list of cut points (len+1 programs)."""
+    return _build_hifigan(sd, p, offline, split16, part, [split_at] if isinstance(split_at, int) else list(split_at))
+
+
+def _build_hifigan(sd, p, offline, split16, part, cuts):
     """HiFiGAN StreamGenerator.decode (HiFiGAN.py:268-296), or with offline=True Generator.forward
     (:141-161).  ext: [zq, y].
 
-    part = 0 / 1 lowers the path as two programs cut in front of upsample stage `split_at` (ext: [zq, mid] and
-    [mid, y], mid = (B, frames*rate, channels) channel-last): consecutive batches can then be software-pipelined
-    over HIP streams, stage 0 of batch i+1 under stage 1 of batch i (bench.py).  Same ops, same arithmetic."""
+    part = k lowers program k of the path cut in front of the upsample stages listed in `cuts` (ext: [in, out] of that
+    program; hand-over tensors are (B, frames*rate, channels) channel-last): consecutive batches can then be
+    software-pipelined over HIP streams, program k of batch i+1 under program k+1 of batch i (bench.py).  Same ops,
+    same arithmetic."""
     specs = arch.hifigan_convs(p)
     b = Builder(sd, specs, offline, split16)
     act, slope = _act_of(p, "LeakyReLU")
@@ -350,10 +356,13 @@ def build_hifigan(sd, p, offline=False, split16=False, part=None, split_at=2):
     if not addl:
         raise NotImplementedError("use_additional_convs=False is not lowered")
     n_up = len(p["upsample_scales"])
-    if part is not None and not 0 < split_at < n_up:
-        raise ValueError("split_at must cut between two upsample stages")
-    first = 0 if part in (None, 0) else split_at
-    last = n_up if part in (None, 1) else split_at
+    if part is not None:
+        if not cuts or sorted(set(cuts)) != list(cuts) or cuts[0] <= 0 or cuts[-1] >= n_up or not 0 <= part <= len(cuts):
+            raise ValueError("cut points must be distinct, ascending and lie between two upsample stages")
+    bounds = [0] + (list(cuts) if part is not None else []) + [n_up]
+    first = bounds[part] if part is not None else 0
+    last = bounds[part + 1] if part is not None else n_up
+    split_at = first
     rate = 1
     if first == 0:
         rz = b.ring(p["in_channels"], 0, rate)
@@ -372,7 +381,7 @@ def build_hifigan(sd, p, offline=False, split16=False, part=None, split_at=2):
         rate *= s
         x0 = b.ring(c, 0, rate)                                 # block input, un-repeated
         b.conv(f"upsamples.{i}", cur, x0, act, slope)           # upsamples[i].inference(act(c))
-        cur = b.ring(c, 0, rate, external=1 if (part == 0 and i == last - 1) else -1)
+        cur = b.ring(c, 0, rate, external=1 if (part is not None and last < n_up and i == last - 1) else -1)
         if multigroup:
             # MultiGroupConv1d.inference (multi_fusion.py:133-141): x.repeat(1, groups, 1) is never
             # materialised -- the first conv and the first residual read the same C channels per group

@@ -404,8 +404,9 @@ class HiFiGANStreamGenerator(_StreamBase):
         self.norm = p["stats"] is not None
         self.hop = arch.hop_length(p)
         self.dim = p["in_channels"]
-        self.stages = 2 if os.environ.get("ADK_VOCODER_STAGES", "1") == "2" else 1
-        self.split_at = 2
+        env = os.environ.get("ADK_VOCODER_STAGES", "1")      # "1", "2" (cut at 2) or explicit cut points "1,2"
+        self.cuts = [] if env == "1" else ([2] if env == "2" else [int(t) for t in env.split(",")])
+        self.stages = len(self.cuts) + 1
         self._dec = None
         self._dec_parts = None
 
@@ -414,14 +415,14 @@ class HiFiGANStreamGenerator(_StreamBase):
         self._dec_parts = None
         self._warm = {}
 
-    def set_stages(self, stages=2, split_at=2):
-        """stages=2 lowers the vocoder as two programs cut in front of upsample stage `split_at`; decode() then runs
-        them back to back, decode_stage(i, x) runs one -- callers that process a sequence of batches can put the two
-        stages on different HIP streams (software pipelining over batches, bench.py).  Same ops, same results."""
-        if stages not in (1, 2):
-            raise ValueError("stages must be 1 or 2")
-        if (stages, split_at) != (self.stages, self.split_at):
-            self.stages, self.split_at = stages, split_at
+    def set_stages(self, cuts=(2,)):
+        """Lower the vocoder as len(cuts)+1 programs cut in front of the upsample stages `cuts` (() = one program);
+        decode() then runs them back to back, decode_stage(i, x) runs one -- callers that process a sequence of batches
+        can put the stages on different HIP streams (software pipelining over batches, bench.py).  Same ops, same
+        results."""
+        cuts = [int(c) for c in cuts]
+        if cuts != self.cuts:
+            self.cuts, self.stages = cuts, len(cuts) + 1
             self._drop_programs()
         return self
 
@@ -435,7 +436,7 @@ class HiFiGANStreamGenerator(_StreamBase):
     def _decoder(self):
         """The whole vocoder as one program (stages == 1)."""
         if self.stages != 1:
-            raise native.NativeError("this generator is lowered in 2 stages: use _decoder_stages()")
+            raise native.NativeError("this generator is lowered in several stages: use _decoder_stages()")
         if self._dec is None:
             self._dec = self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16))
         return self._dec
@@ -444,8 +445,8 @@ class HiFiGANStreamGenerator(_StreamBase):
         if self.stages == 1:
             return [self._decoder()]
         if self._dec_parts is None:
-            self._dec_parts = [self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16, part, self.split_at))
-                               for part in (0, 1)]
+            self._dec_parts = [self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16, part, self.cuts))
+                               for part in range(self.stages)]
         return self._dec_parts
 
     def initial_decoder(self, c):
@@ -456,14 +457,13 @@ class HiFiGANStreamGenerator(_StreamBase):
     def _programs(self):
         if self.stages == 1:
             return {"dec": self._dec}
-        parts = self._dec_parts or [None, None]
-        return {"dec": parts[0], "dec1": parts[1]}
+        parts = self._dec_parts or [None] * self.stages
+        return {("dec" if i == 0 else f"dec{i}"): pr for i, pr in enumerate(parts)}
 
     def decode_stage(self, i, x):
-        """Stage i of a 2-stage lowering: 0: c (B, T, in_channels) -> mid (B, T*rate, channels);
-        1: mid -> (B, 1, T*hop)."""
+        """Program i of a multi-stage lowering: 0 takes c (B, T, in_channels); the last returns (B, 1, T*hop); the
+        hand-over tensors in between are (B, T*rate, channels) channel-last."""
         progs = self._decoder_stages()
-        c_mid, r_mid = program.hifigan_stage_boundary(self.params, self.split_at)
         x = x.to(device=self._dev(), dtype=torch.float32)
         if i == 0:
             if x.dim() != 3 or x.shape[2] != self.dim:
@@ -472,22 +472,25 @@ class HiFiGANStreamGenerator(_StreamBase):
                 x = x.expand(self.num_streams, -1, -1)
             if x.shape[0] != self.num_streams:
                 raise ValueError(f"decode: got {x.shape[0]} streams, this object carries {self.num_streams}")
-            T = x.shape[1]
-            if T == 0:
-                return torch.empty(x.shape[0], 0, c_mid, device=x.device)
-            return self._run_chunks(progs[0], x.contiguous(), 1, self.dim, r_mid, c_mid, T)
-        T = x.shape[1] // r_mid
+            c_in, r_in = self.dim, 1
+        else:
+            c_in, r_in = program.hifigan_stage_boundary(self.params, self.cuts[i - 1])
+        last = i == len(progs) - 1
+        c_out, r_out = (1, self.hop) if last else program.hifigan_stage_boundary(self.params, self.cuts[i])
+        T = x.shape[1] // r_in
         if T == 0:
-            return torch.empty(x.shape[0], 1, 0, device=x.device)
-        y = self._run_chunks(progs[1], x.contiguous(), r_mid, c_mid, self.hop, 1, T)
-        return y.reshape(x.shape[0], 1, T * self.hop)
+            return torch.empty(x.shape[0], 1, 0, device=x.device) if last else torch.empty(x.shape[0], 0, c_out, device=x.device)
+        y = self._run_chunks(progs[i], x.contiguous(), r_in, c_in, r_out, c_out, T)
+        return y.reshape(x.shape[0], 1, T * self.hop) if last else y
 
     def decode(self, c):
         """c (B, T, in_channels) -> (B, 1, T*hop): norm, input conv, upsample stack, output conv, tanh
         (HiFiGAN.py:268-296)."""
         if self.stages == 1:
             return _decode_common(self, self._decoder(), c, self.dim, self.hop)
-        return self.decode_stage(1, self.decode_stage(0, c))
+        for i in range(self.stages):
+            c = self.decode_stage(i, c)
+        return c
 
     def reset_buffer(self):
         for pr in self._programs().values():

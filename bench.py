@@ -65,10 +65,11 @@ class TxRxPipeline:
         self.s_tx, self.s_rx = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         # a vocoder lowered in two stages (set_stages) gets a third stream: its second half of batch i runs under the
         # first half of batch i+1 and the encoder of batch i+2
-        self.two = getattr(ad.decoder, "stages", 1) == 2
-        self.s_rx2 = torch.cuda.Stream(dev) if self.two else None
-        # three programs run concurrently: each stream-K launch assumes half the chip's workgroup slots instead of all
-        # of them (measured: 256 persistent workgroups 210 k frames/s, 384: 203 k, 512: 189 k)
+        self.n_dec = getattr(ad.decoder, "stages", 1)
+        self.two = self.n_dec >= 2
+        self.s_more = [torch.cuda.Stream(dev) for _ in range(self.n_dec - 1)]
+        # several programs run concurrently: each stream-K launch assumes half the chip's workgroup slots instead of all
+        # of them (measured at 3 programs: 256 persistent workgroups 210 k frames/s, 384: 203 k, 512: 189 k)
         if self.two and getattr(ad.decoder, "split16", False):     # (the exact-f32 kernels are matrix-core-bound: whole chip is better)
             wg = int(os.environ.get("ADK_BENCH_WORKGROUPS", "256"))
             ad.tx_encoder.set_workgroups(wg)
@@ -87,15 +88,19 @@ class TxRxPipeline:
             if not self.two:
                 return self.ad.decoder.decode(zq)
             mid = self.ad.decoder.decode_stage(0, zq)
-            ev2 = torch.cuda.Event()
-            ev2.record(self.s_rx)
-        with torch.cuda.stream(self.s_rx2):
-            self.s_rx2.wait_event(ev2)
-            mid.record_stream(self.s_rx2)
-            return self.ad.decoder.decode_stage(1, mid)
+            ev = torch.cuda.Event()
+            ev.record(self.s_rx)
+        for i, st in enumerate(self.s_more, 1):
+            with torch.cuda.stream(st):
+                st.wait_event(ev)
+                mid.record_stream(st)
+                mid = self.ad.decoder.decode_stage(i, mid)
+                ev = torch.cuda.Event()
+                ev.record(st)
+        return mid
 
     def _all(self):
-        return [s for s in (self.s_tx, self.s_rx, self.s_rx2) if s is not None]
+        return [self.s_tx, self.s_rx] + self.s_more
 
     def enter(self):            # all streams start after whatever ran on the current stream
         cur = torch.cuda.current_stream(self.dev)
@@ -239,8 +244,9 @@ def main():
                          "profiles/r1_f16_split_probe.txt).  f32: the exact-f32 MFMA kernels everywhere.  The other one is "
                          "timed too and reported under 'other_precision' (single-GPU runs)")
     ap.add_argument("--no-other-precision", action="store_true")
-    ap.add_argument("--stages", type=int, choices=(1, 2), default=2,
-                    help="2: the vocoder is lowered as two programs and its second half runs on a third HIP stream")
+    ap.add_argument("--stages", type=str, default="2",
+                    help="vocoder lowering: 1 = one program; 2 = two programs cut in front of upsample stage 2, the second on a "
+                         "third HIP stream (default); or explicit cut points, e.g. 1,2 = three programs on three streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cfg1", action="store_true", help="also time BASELINE config 1 (file round trip) on the host CPU")
     ap.add_argument("--no-op-profile", action="store_true")
@@ -351,8 +357,8 @@ def main():
                    "streams_per_gpu": B, "streams_total": world * B, "frames_per_step_per_stream": FPS,
                    "sample_rate": 48000, "hop": HOP, "weights": "seeded synthetic (audiodec_amd/synth.py), fp32",
                    "schedule": "serial, one HIP stream" if args.serial else
-                               ("transmitter (encode+RVQ) and receiver (lookup+vocoder) on two HIP streams, codes handed over by event" if args.stages == 1 else
-                                "3-stage software pipeline over batches on three HIP streams: encode+RVQ | lookup + vocoder stages 0-1 | vocoder stages 2-3 + output, handed over by events")},
+                               ("transmitter (encode+RVQ) and receiver (lookup+vocoder) on two HIP streams, codes handed over by event" if args.stages == "1" else
+                                f"software pipeline over batches on HIP streams, handed over by events: encode+RVQ | lookup + vocoder programs cut in front of upsample stage(s) {'2' if args.stages == '2' else args.stages}")},
         "precision": {"mode": args.precision,
                       "note": "split16: v = hi + lo/2048 with hi = f16(v), lo = f16((v - hi)*2048); sum(a*b) = sum(a_hi*b_hi) + "
                               "(sum(a_hi*b_lo) + sum(a_lo*b_hi))/2048 on v_mfma_f32_32x32x16_f16 with f32 accumulators; measured max "

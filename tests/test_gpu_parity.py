@@ -298,32 +298,36 @@ def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
     assert np.array_equal(one[1], again[1]) and np.array_equal(one[0], again[0]) and np.array_equal(one[3], again[3])
 
 
-@pytest.mark.parametrize("model,split16", [("vctk_v1", False), ("vctk_v1", True), ("vctk_v0", False)])
-def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16):
+@pytest.mark.parametrize("model,split16,stages", [("vctk_v1", False, "2"), ("vctk_v1", True, "2"), ("vctk_v0", False, "2"),
+                                                  ("vctk_v1", True, "1,2,3")])
+def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16, stages):
     """set_stages(2): the vocoder as two programs (cut in front of upsample stage 2) gives bit-identical output,
     back to back or with the halves on different HIP streams (v1: grouped convs + 1x1; v0: three residual blocks
     averaged into the hand-over buffer)."""
     seed, B, hop = 99, 3, 300
     audio = np.stack([synth.synth_audio(seed, s, 4 * hop) for s in range(B)])
     ad1 = load_audiodec(ckpt_root, model, seed, B, 2, split16)
-    os.environ["ADK_VOCODER_STAGES"] = "2"
+    os.environ["ADK_VOCODER_STAGES"] = stages
     try:
         ad2 = load_audiodec(ckpt_root, model, seed, B, 2, split16)
     finally:
         del os.environ["ADK_VOCODER_STAGES"]
-    assert ad1.decoder.stages == 1 and ad2.decoder.stages == 2 and len(ad2.decoder._decoder_stages()) == 2
+    n_st = 2 if stages == "2" else len(stages.split(",")) + 1
+    assert ad1.decoder.stages == 1 and ad2.decoder.stages == n_st and len(ad2.decoder._decoder_stages()) == n_st
     s2 = torch.cuda.Stream(gpu)
     for f0, f1 in ((0, 1), (1, 3), (3, 4)):
         x = torch.from_numpy(audio[:, f0 * hop:f1 * hop])[:, None, :].to(gpu)
         zq = ad1.rx_encoder.lookup(ad1.tx_encoder.quantize(ad1.tx_encoder.encode(x)))
         y1 = ad1.decoder.decode(zq)
-        if f0 == 1:                                           # halves on two streams, handed over by an event
+        if f0 == 1:                                           # first program here, the rest on another stream, handed over by an event
             mid = ad2.decoder.decode_stage(0, zq)
             ev = torch.cuda.Event(); ev.record()
             with torch.cuda.stream(s2):
                 s2.wait_event(ev)
                 mid.record_stream(s2)
-                y2 = ad2.decoder.decode_stage(1, mid)
+                for i in range(1, n_st):
+                    mid = ad2.decoder.decode_stage(i, mid)
+                y2 = mid
             torch.cuda.current_stream().wait_stream(s2)
         else:
             y2 = ad2.decoder.decode(zq)
