@@ -586,7 +586,9 @@ int conv_sk16_pick(const ConvArgs& a) {
     // with the matrix-core time cut to 3/16 the weight / activation re-reads weigh more: 128-row tiles (each X chunk
     // staged once per 128 output channels) win when that still leaves >= 256 tiles (measured: grouped 128-channel
     // vocoder stage 47.7 vs 55.2 us; the 100-tile encoder block loses, 34.6 vs 28.2 us)
-    if (a.cout_g % 128 == 0 && (long long)(a.cout_g / 128) * ((a.n_total + 63) / 64) * a.groups >= 256) return 0;
+    static int wide = -1;                             // ADK_SK16_WIDE=1 (tuning): 128-row tiles whenever the group has >= 128 channels
+    if (wide < 0) { const char* e = getenv("ADK_SK16_WIDE"); wide = e ? atoi(e) : 0; }
+    if (a.cout_g % 128 == 0 && (wide || (long long)(a.cout_g / 128) * ((a.n_total + 63) / 64) * a.groups >= 256)) return 0;
     return (a.cout_g % 64 == 0) ? 2 : 4;
 }
 

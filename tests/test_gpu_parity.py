@@ -339,6 +339,30 @@ def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16, stag
     assert torch.equal(ad1.decoder.decode(zq), ad2.decoder.decode(zq))
 
 
+def test_workgroup_share_changes_only_the_summation_order(gpu, ckpt_root):
+    """adk_program_set_workgroups: fewer persistent workgroups per stream-K launch (what concurrently running programs
+    use) moves the K split points, i.e. only the association of the f32 sums."""
+    from audiodec_amd import native
+    seed, B, hop = 7, 32, 300
+    audio = np.stack([synth.synth_audio(seed, s, 2 * hop) for s in range(B)])
+    ad1 = load_audiodec(ckpt_root, "vctk_v1", seed, B, 1, True)
+    ad2 = load_audiodec(ckpt_root, "vctk_v1", seed, B, 1, True)
+    ad2.tx_encoder.set_workgroups(64)
+    ad2.decoder.set_workgroups(64)
+    assert ad2.decoder._decoder().lib.adk_program_set_workgroups(ad2.decoder._decoder().h, 3) != 0     # 0 or >= 8
+    for f in range(2):
+        x = torch.from_numpy(audio[:, f * hop:(f + 1) * hop])[:, None, :].to(gpu)
+        outs = []
+        for ad in (ad1, ad2):
+            idx = ad.tx_encoder.quantize(ad.tx_encoder.encode(x))
+            outs.append((idx, ad.decoder.decode(ad.rx_encoder.lookup(idx))))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-5
+    flags = __import__("ctypes").c_int32(0)
+    native.check(native.lib().adk_debug_flags(__import__("ctypes").byref(flags)), "flags")
+    assert flags.value == 0
+
+
 def test_transmitter_receiver_on_two_hip_streams(gpu, ckpt_root):
     """bench.py's schedule: encode+RVQ on one HIP stream, lookup+vocoder on another, codes handed over by an
     event (the reference's two streamer threads).  Concurrent stream-K kernels must not disturb each other."""
