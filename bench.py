@@ -136,15 +136,45 @@ def op_profile(ad, xs, streams, n_steps, fps=1):
             if op.kind == 0:
                 c = op.conv
                 flops = 2.0 * c.groups * c.cout_g * c.taps * c.cin_g * op.rate_out * streams * fps
-            rows.append(dict(prog=k, name=p.op_names[i], kernel=p.describe_op(i, fps), ms=acc[k][i] / n_steps, flops=flops, op=op))
+            nbytes = 0.0
+            if op.kind == 0:
+                # compulsory bytes of the launch: input rows incl. history (once), weights (once), outputs, residual
+                c = op.conv
+                cin_tot = c.cin_g * (c.groups if c.in_group_stride else 1)
+                t_out = op.rate_out * fps
+                nbytes = 4.0 * (streams * (t_out * c.stride + c.hist) * cin_tot + c.groups * c.cout_g * c.taps * c.cin_g
+                                + streams * t_out * c.groups * c.cout_g * (2 if op.res_ring >= 0 else 1))
+            rows.append(dict(prog=k, name=p.op_names[i], kernel=p.describe_op(i, fps), ms=acc[k][i] / n_steps, flops=flops, bytes=nbytes, op=op))
     return rows
+
+
+def pmc_traffic(dom, split16):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads, + WRITE_SIZE), averaged over its 256-stream launches
+    (grid = 512 workgroups).  PMC counters cannot be collected from inside this process; None when the file is absent."""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", "r1_pmc_split16_traffic.csv" if split16 else "r1_pmc_summary.csv")
+    m = re.match(r"conv_sk(16)?<(\d+)x(\d+)>", dom)
+    if not os.path.exists(path) or not m:
+        return None
+    cfg = {"64x64": "<2, 2, 1,", "128x64": "<4, 1, 2,", "32x128": "<1, 4, 1,"}.get(f"{m.group(2)}x{m.group(3)}")
+    if cfg is None:
+        return None
+    num = den = 0.0
+    for r in csv.DictReader(open(path)):
+        if "conv_sk_kernel" + cfg in r["kernel"] and int(r["grid_threads"]) == 131072 and (("true" in r["kernel"]) == bool(split16)):
+            n = float(r["launches"])
+            num += n * (float(r["FETCH_KB_x2_corrected"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
+            den += n
+    return round(num / den) if den else None
 
 
 def roofline_from(rows, streams, fps=1, split16=False):
     by = {}
     for r in rows:
-        d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0))
-        d["ms"] += r["ms"]; d["flops"] += r["flops"]; d["launches"] += 1
+        d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
+        d["ms"] += r["ms"]; d["flops"] += r["flops"]; d["launches"] += 1; d["bytes"] += r.get("bytes", 0.0)
     dom = max(by, key=lambda k: by[k]["ms"])
     d = by[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
@@ -152,7 +182,9 @@ def roofline_from(rows, streams, fps=1, split16=False):
     # MFMA, or -- for the split-f16 kernels -- the dense f16 MFMA peak divided by the 3 instructions per product sum
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom, split16),
+            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+            "traffic_note": "bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes (profiles/), not collected live",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
             "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
