@@ -170,6 +170,26 @@ def pmc_traffic(dom, split16):
     return round(num / den) if den else None
 
 
+def full_grid_bytes(rows, dom, streams, fps):
+    """Mean compulsory bytes over the launches of kernel `dom` whose stream-K grid is the full 512 workgroups
+    (G = min(512, ceil(tiles * chunks / 2)), conv_mfma.hip launch_cfg)."""
+    import re
+    m = re.match(r"conv_sk(16)?<(\d+)x(\d+)>", dom)
+    if not m:
+        return None
+    bm, bn = int(m.group(2)), int(m.group(3))
+    sel = []
+    for r in rows:
+        if r["kernel"] != dom or r["op"].kind != 0:
+            continue
+        c = r["op"].conv
+        n = streams * r["op"].rate_out * fps
+        units = -(-c.cout_g // bm) * -(-n // bn) * c.groups * -(-(c.taps * c.cin_g) // 64)
+        if (units + 1) // 2 >= 512:
+            sel.append(r["bytes"])
+    return round(sum(sel) / len(sel)) if sel else None
+
+
 def roofline_from(rows, streams, fps=1, split16=False):
     by = {}
     for r in rows:
@@ -183,8 +203,10 @@ def roofline_from(rows, streams, fps=1, split16=False):
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom, split16),
-            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-            "traffic_note": "bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes (profiles/), not collected live",
+            "algorithmic_bytes_per_launch": full_grid_bytes(rows, dom, streams, fps),
+            "traffic_note": "both per launch, over the launches of this kernel that use the full 512-workgroup grid (the only ones the PMC "
+                            "file can tell from B=1 / warm-up launches): traffic = FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
+                            "(profiles/r1_pmc_*), not collected live; algorithmic = input rows incl. history + weights + outputs (+ residual), once each",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
             "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
