@@ -61,7 +61,7 @@ __device__ __forceinline__ f16x8 as_f16x8(const u32x4s& v) {
 // NW waves per workgroup; each wave owns work items (m-tile, pair of consecutive n-tiles) and keeps each
 // weight fragment in registers for both n-tiles.  PF = weight prefetch distance in 16-k chunks.
 template <int C, int ACT, int TAPS, int NW, int PF>
-__global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16Args rl) {
+__global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3)) void conv_rl16_kernel(ConvArgs a, Rl16Args rl) {   // all-weights-up-front variants: 256 VGPRs
     constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
     constexpr int CH = C / 16;                         // 16-k chunks per tap
     constexpr int STEPS = TAPS * CH;
@@ -80,6 +80,37 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
     const int tcur = min(rl.tt, a.t_out - t0);
     const int n_tiles = (tcur + 31) >> 5;
 
+    // ---- work items of this wave, and the weight fragments of its FIRST item: issued before the rows are staged, so the
+    // L2 round trip of the weights overlaps the one of the rows (for short K -- PF >= STEPS -- that is all the weights) ----
+    const int m_tiles = rl.mt32_per_g;
+    const int n_pairs = (n_tiles + 1) >> 1;
+    const int items = m_tiles * n_pairs;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, rl.w_bytes, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int rot = (wave + blockIdx.x + (blockIdx.x >> 8)) % NW;
+    u32x4s ah[PF + 1], al[PF + 1];
+    auto preload = [&](unsigned wb) {
+#pragma unroll
+        for (int s = 0; s < PF && s < STEPS; ++s) {
+            ah[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wb + (unsigned)s * 2048u, 0);
+            al[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wb + (unsigned)s * 2048u, 0);
+        }
+    };
+    const int first_mt = rot / n_pairs;
+    if (rot < items) preload((unsigned)((g * m_tiles + first_mt) * rl.ksteps) * 2048u);
+    // bias of this wave's first item: fetched now, not in the epilogue (one less dependent round trip before the stores)
+    // (short-K variants only: the long-K ones have no registers to spare)
+    constexpr bool EARLY_BIAS = (PF > 4 || PF >= STEPS);
+    float4 bias0[EARLY_BIAS ? 4 : 1];
+    if constexpr (EARLY_BIAS) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            bias0[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ml = first_mt * 32 + 8 * qd + 4 * lh;
+            if (a.bias && rot < items && ml < a.cout_g) bias0[qd] = *reinterpret_cast<const float4*>(a.bias + g * a.cout_g + ml);
+        }
+    }
+
     // ---- stage rows [t0 - span, t0 + 32*n_tiles): activation, split into hi / lo halves ----
     {
         const float* xin = a.in + (size_t)b * a.in_rows * a.in_ch + a.in_choff + g * a.in_gstride;
@@ -87,11 +118,13 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
         const int rows_all = rl.span + 32 * n_tiles;
         constexpr int C8 = C / 8;
         const int items = rows_all * C8;
-        for (int i0 = tid; i0 < items; i0 += 2 * NT) {          // two items per pass: both loads in flight together
-            float4 u[2], v[2];
-            int rr[2], c8[2];
+        constexpr int SB = (PF > 4 || PF >= STEPS) ? 4 : 2;     // items per pass: their loads are in flight together (the short-K
+                                                                // variants have the registers to take a whole tile in one round trip)
+        for (int i0 = tid; i0 < items; i0 += SB * NT) {
+            float4 u[SB], v[SB];
+            int rr[SB], c8[SB];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < SB; ++k) {
                 const int i = i0 + k * NT;
                 rr[k] = i / C8; c8[k] = i - rr[k] * C8;
                 u[k] = v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < SB; ++k) {
                 if (i0 + k * NT >= items) break;
                 float4 uu = u[k], vv = v[k];
                 uu.x = rl16_act<ACT>(uu.x, a.slope); uu.y = rl16_act<ACT>(uu.y, a.slope);
@@ -120,13 +153,6 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
     }
     __syncthreads();
 
-    const int m_tiles = rl.mt32_per_g;
-    const int n_pairs = (n_tiles + 1) >> 1;
-    const int items = m_tiles * n_pairs;
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, rl.w_bytes, 0x00020000);
-    const unsigned lane16 = (unsigned)lane * 16u;
-    const int rot = (wave + blockIdx.x + (blockIdx.x >> 8)) % NW;
-
     for (int item = rot; item < items; item += NW) {
         const int mt = item / n_pairs, nt0 = 2 * (item - mt * n_pairs);
         const bool two = nt0 + 1 < n_tiles;
@@ -137,12 +163,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
         const unsigned char* x0 = xs + (nt0 * 32 + l31) * RS + 16 * lh;
         const unsigned char* x1 = x0 + 32 * RS;
 
-        u32x4s ah[PF + 1], al[PF + 1];
-#pragma unroll
-        for (int s = 0; s < PF && s < STEPS; ++s) {
-            ah[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wbase + (unsigned)s * 2048u, 0);
-            al[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wbase + (unsigned)s * 2048u, 0);
-        }
+        if (item != rot) preload(wbase);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             if (s + PF < STEPS && !(ADK_RL16_DBG & 1)) {
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, 3) void conv_rl16_kernel(ConvArgs a, Rl16A
                                        fmaf(ac[4 * qd + 2], kLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kLoInv, am[4 * qd + 3]));
                 bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
                 if (a.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + g * a.cout_g + ml);
+                    const float4 bb = (EARLY_BIAS && item == rot) ? bias0[EARLY_BIAS ? qd : 0] : *reinterpret_cast<const float4*>(a.bias + g * a.cout_g + ml);
                     v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
                 }
                 if (resp) {
@@ -307,11 +328,15 @@ int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
         ADK_HIP_CHECK(hipGetLastError());
         return ADK_OK;
     };
-    constexpr int PF = 2;                             // 3 spills at the 168-VGPR budget of 3 workgroups per CU
+    // weight prefetch distance in 16-k chunks: 2 for the long-K layers (3 spills at the 168-VGPR budget of 3 workgroups
+    // per CU); short K (<= 8 chunks: 1x1 convs, the 2-tap transposed convs) takes ALL its weight fragments up front, in
+    // the same round trip as the rows
+    constexpr int PF = 2;
+    constexpr int S1 = 1 * C / 16, S2 = 2 * C / 16;
     auto by_taps = [&](auto act) -> int {
         constexpr int ACT = decltype(act)::value;
-        if (a.taps == 1) return go(conv_rl16_kernel<C, ACT, 1, NW, PF>);
-        if (a.taps == 2) return go(conv_rl16_kernel<C, ACT, 2, NW, PF>);
+        if (a.taps == 1) return go(conv_rl16_kernel<C, ACT, 1, NW, S1>);
+        if (a.taps == 2) return go(conv_rl16_kernel<C, ACT, 2, NW, S2>);
         if (a.taps == 3) return go(conv_rl16_kernel<C, ACT, 3, NW, PF>);
         if (a.taps == 7) return go(conv_rl16_kernel<C, ACT, 7, NW, PF>);
         return go(conv_rl16_kernel<C, ACT, 11, NW, PF>);
@@ -334,6 +359,11 @@ int launch_conv_rl16(const ConvArgs& a, hipStream_t s) {
     // layers) into two balanced halves -- twice the workgroups, two dispatch rounds whose load / matrix-core / store
     // phases overlap instead of running in lockstep (measured 38.0 -> 34.2 us; shorter tiles lose to the re-staged history)
     if (tt >= a.t_out && (a.t_out + 31) / 32 >= 8) tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
+    // ... and a short one whose (m-tile, n-tile pair) items would need two passes of the 4 waves (the 64 -> 32 transposed
+    // conv: 3 m-tiles x 2 pairs) when halving it leaves at most one item per wave
+    else if (tt >= a.t_out && (a.t_out + 31) / 32 >= 4 && (a.cout_g / 32) * (((a.t_out + 31) / 32 + 1) / 2) > 4 &&
+             (a.cout_g / 32) * ((((a.t_out + 31) / 32 + 1) / 2 + 1) / 2) <= 4)
+        tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
     { static int tt_env = -1; if (tt_env < 0) { const char* e = getenv("ADK_RL16_TT"); tt_env = e ? atoi(e) : 0; }
       if (tt_env >= 32 && tt_env < tt) tt = tt_env / 32 * 32; }          // tuning: shorter time tiles (more, smaller workgroups)
     // work items of a workgroup = m-tiles x pairs of n-tiles; 5 waves when that is a multiple of 5 (the 300-step

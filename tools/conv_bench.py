@@ -20,7 +20,7 @@ SHAPES = {  # cin_g, cout_g, groups, taps, stride, dil, t_out, up, act
     "s2": (64, 64, 3, 11, 1, 5, 100, 1, 2), "s3": (32, 32, 3, 11, 1, 5, 300, 1, 2),
     "e3": (256, 256, 1, 7, 1, 9, 5, 1, 1), "e2": (128, 128, 1, 7, 1, 9, 25, 1, 1),
     "e1": (64, 64, 1, 7, 1, 9, 100, 1, 1), "e0": (32, 32, 1, 7, 1, 9, 300, 1, 1),
-    "up0": (512, 1280, 1, 2, 1, 1, 1, 5, 2), "up3": (64, 96, 1, 2, 1, 1, 100, 3, 2), "up3s": (64, 96, 1, 2, 1, 1, 100, 3, 0),
+    "up0": (512, 1280, 1, 2, 1, 1, 1, 5, 2), "up3": (64, 96, 1, 2, 1, 1, 100, 3, 2), "up3s": (64, 96, 1, 2, 1, 1, 100, 3, 0), "up3x5": (64, 96, 1, 2, 1, 1, 500, 3, 2), "up3x20": (64, 96, 1, 2, 1, 1, 2000, 3, 2),
     "r0": (32, 32, 1, 1, 1, 1, 300, 1, 1), "r1": (64, 64, 1, 1, 1, 1, 100, 1, 1),
     "d3": (256, 512, 1, 10, 5, 1, 1, 1, 0), "p": (512, 64, 1, 3, 1, 1, 1, 1, 0),
 }
