@@ -11,6 +11,7 @@ from typing import Union
 
 import torch
 
+from . import native
 from .configs import assign_model  # noqa: F401  (utils/audiodec.py:109-179)
 from .stream import AudioCodec, AudioCodecStreamer
 from .stream_generator import AutoEncoderStreamGenerator as generator_audiodec
@@ -27,6 +28,10 @@ class AudioDec(AudioCodec):
         max_frames: int = 16,
     ):
         super(AudioDec, self).__init__(tx_device=tx_device, rx_device=rx_device, receptive_length=receptive_length)
+        # The signature keeps the reference's 'cpu' defaults (utils/audiodec.py:20-30) so that keyword callers port
+        # unchanged, but this package has no CPU compute path: say so here, not at the first kernel launch.
+        for d in (tx_device, rx_device):
+            native.require_gpu(d)
         self.num_streams = num_streams
         self.max_frames = max_frames
 

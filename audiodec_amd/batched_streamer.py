@@ -21,6 +21,8 @@ import time
 import numpy as np
 import torch
 
+from . import native
+
 
 class BatchedAudioDecStreamer:
     def __init__(self, audiodec, frame_size, sample_rate=48000, gain=1.0, max_latency=0.1, use_wire_format=True):
@@ -86,6 +88,7 @@ class BatchedAudioDecStreamer:
             zq = self.rx.lookup_packed(payload) if self.use_wire else self.rx.lookup(idx)
             y = self.dec.decode(zq)
             out = y[:, 0].cpu().numpy()
+        native.raise_on_device_flags("BatchedAudioDecStreamer.tick")     # the copy synchronised: surface device-side failures
         t2 = time.time()
         self.encoder_times.append(t1 - t0)
         self.decoder_times.append(t2 - t1)

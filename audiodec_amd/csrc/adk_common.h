@@ -61,7 +61,27 @@ int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
 int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
-int* flags_word();                                   // device address of the sticky debug/error flags
+int* flags_word();                                   // address of the sticky debug/error flags ON THE CURRENT DEVICE
+constexpr int kMaxDevices = 64;
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
+// Makes `device` current for the lifetime of the object (programs are bound to the device they were created on,
+// whatever device the calling thread has current); restores the previous one.
+// device that owns a device pointer (the current device when the runtime does not know the pointer)
+inline int device_of(const void* ptr) {
+    hipPointerAttribute_t at;
+    if (ptr && hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeDevice && at.device >= 0 && at.device < kMaxDevices)
+        return at.device;
+    (void)hipGetLastError();
+    return current_device();
+}
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != device) { if (hipSetDevice(device) == hipSuccess) prev = cur; }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 int launch_pack_weights(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 bool conv_mfma_supported(const ConvArgs& a);
 int conv_mfma_pick(const ConvArgs& a);

@@ -520,7 +520,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (sk.epoch == 0) sk.epoch = ++ws.epoch;
     sk.err = flags_word();
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
+        static bool attr_set_dev[kMaxDevices] = {};      // function attributes are per device
+        bool& attr_set = attr_set_dev[current_device()];
         if (!attr_set) {
             ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -104,6 +104,21 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
     return launch_conv_direct(a, s);
 }
 
+// name of the kernel run_conv would launch for these arguments (profiles, tests)
+static std::string conv_kernel_name(const ConvArgs& a, int impl) {
+    if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
+    if (impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK) {
+        const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
+        if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
+        return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
+    }
+    const bool mf = impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (impl == ADK_IMPL_MFMA || impl == ADK_IMPL_MFMA_ROWS || a.groups * a.cout_g >= 32);
+    const bool rl = mf && ((impl == ADK_IMPL_MFMA_ROWS && conv_rl_supported(a)) || (impl == ADK_IMPL_AUTO && g_use_rl && conv_rl_preferred(a)));
+    if (rl) return a.cin_g == 32 ? "conv_rl<32>" : "conv_rl<64>";
+    if (mf) return conv_mfma_cfg_name(conv_mfma_pick(a));
+    return a.groups * a.cout_g == 1 ? "conv_cout1" : (a.cin_g == 1 && a.taps == 7 ? "conv_cin1" : "conv_direct");
+}
+
 }  // namespace adk
 
 using namespace adk;
@@ -118,8 +133,19 @@ extern "C" int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_rin
     ConvArgs a;
     int rc = build_args(*d, in, out, res, batch, t_out, a);
     if (rc != ADK_OK) return rc;
-    static thread_local Workspace tls_ws;             // op-level calls: one scratch per host thread
-    return run_conv(a, impl, static_cast<hipStream_t>(stream), tls_ws);
+    DeviceGuard guard(device_of(out.base));
+    static thread_local Workspace tls_ws[kMaxDevices];   // op-level calls: one scratch per host thread and device
+    return run_conv(a, impl, static_cast<hipStream_t>(stream), tls_ws[current_device()]);
+}
+
+extern "C" int adk_causal_conv_describe(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
+                                        int32_t batch, int32_t t_out, int32_t impl, char* buf, int32_t n) {
+    if (!d || !buf || n <= 0) return fail(ADK_ERR_ARG, "adk_causal_conv_describe: null argument");
+    ConvArgs a;
+    int rc = build_args(*d, in, out, res, batch, t_out, a);
+    if (rc != ADK_OK) return rc;
+    snprintf(buf, n, "%s", conv_kernel_name(a, impl).c_str());
+    return ADK_OK;
 }
 
 extern "C" int64_t adk_packed_weight_floats(int32_t groups, int32_t cout_g, int32_t ktot) {
@@ -130,6 +156,7 @@ extern "C" int64_t adk_packed_weight_floats(int32_t groups, int32_t cout_g, int3
 extern "C" int adk_pack_weights_mfma(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream) {
     if (!w || !out) return fail(ADK_ERR_ARG, "adk_pack_weights_mfma: null pointer");
     if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 8) return fail(ADK_ERR_SHAPE, "adk_pack_weights_mfma: need ktot % 8 == 0");
+    DeviceGuard guard(device_of(out));
     return launch_pack_weights(w, out, groups, cout_g, ktot, static_cast<hipStream_t>(stream));
 }
 
@@ -141,6 +168,7 @@ extern "C" int64_t adk_packed_weight_floats_split16(int32_t groups, int32_t cout
 extern "C" int adk_pack_weights_split16(const float* w, float* out, int32_t groups, int32_t cout_g, int32_t ktot, void* stream) {
     if (!w || !out) return fail(ADK_ERR_ARG, "adk_pack_weights_split16: null pointer");
     if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 16) return fail(ADK_ERR_SHAPE, "adk_pack_weights_split16: need ktot % 16 == 0");
+    DeviceGuard guard(device_of(out));
     return launch_pack_split16(w, out, groups, cout_g, ktot, static_cast<hipStream_t>(stream));
 }
 
@@ -151,6 +179,7 @@ struct adk_program {
     std::vector<int32_t> rows;      // ring length (arena rings)
     std::vector<int32_t> cursor;
     int batch = 0, max_frames = 0, n_ext = 0;
+    int device = 0;                 // HIP device the program lives on (the owner of its arena)
     const float* weights = nullptr; int64_t weights_floats = 0;
     float* arena = nullptr; int64_t arena_floats = 0;
     Workspace ws;
@@ -171,6 +200,15 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
     p->rings.assign(rings, rings + n_rings);
     p->rows.resize(n_rings); p->cursor.assign(n_rings, 0);
     p->batch = batch; p->max_frames = max_frames;
+    p->device = current_device();
+    {   // a program lives on the device that owns its arena, whatever device the calling thread has current
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, arena) == hipSuccess && at.type == hipMemoryTypeDevice && at.device >= 0 && at.device < kMaxDevices)
+            p->device = at.device;
+        else
+            (void)hipGetLastError();          // not a device pointer known to the runtime: keep the current device
+    }
+    DeviceGuard guard(p->device);
     p->weights = weights; p->weights_floats = weights_floats; p->arena = arena; p->arena_floats = arena_floats;
     auto bail = [&](int code, const std::string& m) { delete p; return fail(code, m); };
     for (int i = 0; i < n_rings; ++i) {
@@ -236,6 +274,7 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
 
 extern "C" void adk_program_destroy(adk_program* p) {
     if (!p) return;
+    DeviceGuard guard(p->device);
     if (p->ws.ptr) (void)hipFree(p->ws.ptr);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -261,6 +300,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
     for (int i = 0; i < p->n_ext; ++i)
         if (!ext[i]) return fail(ADK_ERR_ARG, "program_step: null external buffer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    DeviceGuard guard(p->device);            // launches, the workspace and the flag word belong to the program's device
     const int n_ops = (int)p->ops.size();
     if (p->profiling && (int)p->ev.size() != n_ops + 1) {
         for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -337,18 +377,7 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         ConvArgs a;
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
-        if (o.impl == ADK_IMPL_SPLIT16 || o.impl == ADK_IMPL_SPLIT16_ROWS || o.impl == ADK_IMPL_SPLIT16_SK) {
-            if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
-            const bool rows = o.impl == ADK_IMPL_SPLIT16_ROWS || (o.impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
-            std::string nm = rows ? (a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>") : std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
-            snprintf(buf, n, "%s", nm.c_str());
-            return ADK_OK;
-        }
-        const bool mf = o.impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (o.impl == ADK_IMPL_MFMA || a.groups * a.cout_g >= 32);
-        if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
-        const bool rl = mf && ((o.impl == ADK_IMPL_MFMA_ROWS && conv_rl_supported(a)) || (o.impl == ADK_IMPL_AUTO && g_use_rl && conv_rl_preferred(a)));
-        if (rl) name = a.cin_g == 32 ? "conv_rl<32>" : "conv_rl<64>";
-        else name = mf ? conv_mfma_cfg_name(conv_mfma_pick(a)) : (a.groups * a.cout_g == 1 ? "conv_cout1" : (a.cin_g == 1 && a.taps == 7 ? "conv_cin1" : "conv_direct"));
+        name = conv_kernel_name(a, o.impl);
     }
     snprintf(buf, n, "%s", name.c_str());
     return ADK_OK;
@@ -356,6 +385,7 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
 
 extern "C" int adk_program_reset(adk_program* p, void* stream) {
     if (!p) return fail(ADK_ERR_ARG, "program_reset: null program");
+    DeviceGuard guard(p->device);
     for (size_t i = 0; i < p->rings.size(); ++i) {
         const adk_ring_desc& r = p->rings[i];
         if (r.external >= 0) continue;
@@ -398,6 +428,7 @@ extern "C" int adk_program_set_profiling(adk_program* p, int32_t enabled) {
 extern "C" int adk_program_last_op_ms(adk_program* p, float* ms, int32_t n) {
     if (!p || !ms || n != (int)p->ops.size()) return fail(ADK_ERR_ARG, "program_last_op_ms: bad arguments");
     if (!p->profiling || (int)p->ev.size() != n + 1) return fail(ADK_ERR_STATE, "program_last_op_ms: profiling not enabled / no step yet");
+    DeviceGuard guard(p->device);
     ADK_HIP_CHECK(hipEventSynchronize(p->ev[n]));
     for (int i = 0; i < n; ++i) ADK_HIP_CHECK(hipEventElapsedTime(&ms[i], p->ev[i], p->ev[i + 1]));
     return ADK_OK;

@@ -11,10 +11,12 @@ constexpr int RVQ_DIM_MAX = 128;
 
 __device__ int g_adk_flags = 0;      // bit 0: rvq_lookup saw an out-of-range index; bit 1: stream-K publish flag timeout
 
+static int* g_flag_ptr[kMaxDevices] = {};   // one word per device: the symbol's address differs from device to device
+
 int* flags_word() {
-    static int* p = nullptr;
-    if (!p) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_adk_flags));
-    return p;
+    const int d = current_device();
+    if (!g_flag_ptr[d]) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&g_flag_ptr[d]), HIP_SYMBOL(g_adk_flags));
+    return g_flag_ptr[d];
 }
 
 // (value, index) arg-max with "greater value, else smaller index" -- matches `(-dist).max(1)` on the
@@ -238,6 +240,7 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
         return fail(ADK_ERR_ARG, "adk_rvq_encode: embed/enorm must be 16-byte aligned");
     if (n_rows == 0) return ADK_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    DeviceGuard guard(device_of(z));
     constexpr int RB = 4;
     hipLaunchKernelGGL(rvq_encode_kernel<RB>, dim3((n_rows + RB - 1) / RB), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
                        reinterpret_cast<long long*>(idx), zq, n_rows, n_q, dim, size);
@@ -252,6 +255,7 @@ extern "C" int adk_rvq_lookup(const int64_t* idx, const float* codebook, float* 
     if ((reinterpret_cast<uintptr_t>(codebook) | reinterpret_cast<uintptr_t>(zq)) & 15)
         return fail(ADK_ERR_ARG, "adk_rvq_lookup: codebook/zq must be 16-byte aligned");
     if (n_rows == 0) return ADK_OK;
+    DeviceGuard guard(device_of(zq));
     const long long total = (long long)n_rows * (dim / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -268,6 +272,7 @@ extern "C" int adk_ring_write(const float* src, adk_ring_view ring, const float*
     if (batch < 0 || t < 0 || t > ring.rows || ring.cursor < 0 || ring.cursor >= ring.rows || ring.ch_off != 0)
         return fail(ADK_ERR_SHAPE, "adk_ring_write: bad ring geometry (full rows only: ch_off must be 0)");
     if (batch == 0 || t == 0) return ADK_OK;
+    DeviceGuard guard(device_of(ring.base));
     const int src_ch = ring.channels;
     const long long total = (long long)batch * t * src_ch;
     long long blocks = (total + 255) / 256;
@@ -279,10 +284,17 @@ extern "C" int adk_ring_write(const float* src, adk_ring_view ring, const float*
 }
 
 extern "C" int adk_debug_flags(int32_t* out) {
-    int v = 0;
-    ADK_HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(adk::g_adk_flags), sizeof(int)));
-    int zero = 0;
-    ADK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(adk::g_adk_flags), &zero, sizeof(int)));
-    if (out) *out = v;
+    // OR of the flag words of every device this library has launched on (plus the current one); each is cleared
+    int all = 0;
+    const int here = current_device();
+    for (int d = 0; d < kMaxDevices; ++d) {
+        if (!g_flag_ptr[d] && d != here) continue;
+        DeviceGuard guard(d);
+        int v = 0, zero = 0;
+        ADK_HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(adk::g_adk_flags), sizeof(int)));
+        if (v) ADK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(adk::g_adk_flags), &zero, sizeof(int)));
+        all |= v;
+    }
+    if (out) *out = all;
     return ADK_OK;
 }

@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void codes_pack_kernel(const long long* __rest
         unsigned v = 0;
         int q = b0 / bits;
         while (q < n_q && q * bits < b0 + 8) {
-            const unsigned long long c = code_of(idx, q, row, n_rows, size);
-            if (c >= (unsigned long long)size) atomicOr(flags, 4);          // not a code of stage q
+            unsigned long long c = code_of(idx, q, row, n_rows, size);
+            if (c >= (unsigned long long)size) { atomicOr(flags, 4); c = 0; }   // not a code of stage q: flag it and keep it out of
+                                                                               // the neighbouring codes' bits (packs as code 0)
             const int shift = q * bits - b0;           // position of the code's bit 0 relative to this byte
             v |= shift >= 0 ? (unsigned)((c << shift) & 0xffull) : (unsigned)((c >> (-shift)) & 0xffull);
             ++q;
@@ -97,6 +98,7 @@ extern "C" int adk_codes_pack(const int64_t* idx, uint8_t* out, int32_t n_rows, 
     if (rc != ADK_OK || n_rows == 0) return rc;              // an empty batch of frames is fine (and has no pointers)
     if (!idx || !out) return fail(ADK_ERR_ARG, "adk_codes_pack: null pointer");
     const int fb = (n_q * bits + 7) / 8;
+    DeviceGuard guard(device_of(out));
     hipLaunchKernelGGL(codes_pack_kernel, dim3(grid_for((long long)n_rows * fb)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const long long*>(idx), out, n_rows, n_q, bits, size, fb, flags_word());
     ADK_HIP_CHECK(hipGetLastError());
@@ -108,6 +110,7 @@ extern "C" int adk_codes_unpack(const uint8_t* in, int64_t* idx, int32_t n_rows,
     if (rc != ADK_OK || n_rows == 0) return rc;
     if (!idx || !in) return fail(ADK_ERR_ARG, "adk_codes_unpack: null pointer");
     const int fb = (n_q * bits + 7) / 8;
+    DeviceGuard guard(device_of(idx));
     hipLaunchKernelGGL(codes_unpack_kernel, dim3(grid_for((long long)n_rows * n_q)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        in, reinterpret_cast<long long*>(idx), n_rows, n_q, bits, size, fb);
     ADK_HIP_CHECK(hipGetLastError());
@@ -125,6 +128,7 @@ extern "C" int adk_codes_lookup(const uint8_t* in, const float* codebook, float*
         return fail(ADK_ERR_ARG, "adk_codes_lookup: codebook/zq must be 16-byte aligned");
     if (n_rows == 0) return ADK_OK;
     const int fb = (n_q * bits + 7) / 8;
+    DeviceGuard guard(device_of(zq));
     hipLaunchKernelGGL(codes_lookup_kernel, dim3(grid_for((long long)n_rows * (dim / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        in, codebook, zq, n_rows, n_q, bits, size, fb, dim, flags_word());
     ADK_HIP_CHECK(hipGetLastError());

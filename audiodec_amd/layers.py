@@ -66,8 +66,15 @@ class _CausalBase:
                                                  None, None, B, L, native.current_stream(self.dev)), "adk_ring_write")
         return L
 
-    def _run(self, d, t_out, out_rows, out_ch):
+    def _run(self, d, t_out, out_rows, out_ch, residual=None):
         out = torch.empty(self.batch, out_rows, out_ch, device=self.dev)
+        res_view = _view(None, 0, 0, 0)
+        if residual is not None:
+            # fused epilogue add (x + conv(...): residual_unit.py:78-81, residual_block.py:103): residual (B, Cout, T)
+            if tuple(residual.shape) != (self.batch, out_ch, t_out) or out_rows != t_out:
+                raise ValueError(f"residual must be ({self.batch}, {out_ch}, {t_out})")
+            res = residual.to(self.dev, torch.float32).transpose(1, 2).contiguous()
+            res_view = _view(res, t_out, out_ch, 0)
         d.act_in, d.act_in_slope, d.act_out = self.act_in, self.slope, self.act_out
         d.w = self.w_packed.data_ptr()
         d.w_frag = self.w_frag.data_ptr() if self.w_frag is not None else None
@@ -76,9 +83,13 @@ class _CausalBase:
                 raise ValueError("this layer shape has no split-f16 kernel")
             d.w_frag = self.w_split.data_ptr()
         d.bias = self.b_packed.data_ptr() if self.b_packed is not None else None
+        in_view, out_view = _view(self.ring, self.rows, self.in_channels, self.cursor), _view(out, out_rows, out_ch, 0)
+        buf = C.create_string_buffer(64)
+        native.check(native.lib().adk_causal_conv_describe(C.byref(d), in_view, out_view, res_view, self.batch, t_out, self.impl, buf, 64),
+                     "adk_causal_conv_describe")
+        self.last_kernel = buf.value.decode()          # which kernel this call runs (tests, profiles)
         native.check(native.lib().adk_causal_conv(
-            C.byref(d), _view(self.ring, self.rows, self.in_channels, self.cursor), _view(out, out_rows, out_ch, 0),
-            _view(None, 0, 0, 0), self.batch, t_out, self.impl, native.current_stream(self.dev)), "adk_causal_conv")
+            C.byref(d), in_view, out_view, res_view, self.batch, t_out, self.impl, native.current_stream(self.dev)), "adk_causal_conv")
         return out
 
 
@@ -107,7 +118,8 @@ class CausalConv1d(_CausalBase):
         self.b_packed = self.bias.to(self.dev) if self.bias is not None else None
         return self
 
-    def inference(self, x):
+    def inference(self, x, residual=None):
+        """x (B, Cin, L) -> (B, Cout, L/stride); `residual` (B, Cout, L/stride), if given, is added in the kernel's epilogue."""
         L = self._push(x)
         if L % self.stride:
             raise ValueError(f"chunk length {L} is not a multiple of the stride {self.stride}")
@@ -117,7 +129,7 @@ class CausalConv1d(_CausalBase):
         d.taps, d.stride, d.dilation, d.hist = self.kernel_size, self.stride, self.dilation, self.hist
         d.up, d.cout_real = 1, self.out_channels
         d.in_group_stride, d.res_group_stride = d.cin_g, d.cout_g
-        out = self._run(d, t_out, t_out, self.out_channels)
+        out = self._run(d, t_out, t_out, self.out_channels, residual)
         self.cursor = (self.cursor + L) % self.rows
         return out.transpose(1, 2)
 

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -52,6 +52,7 @@ SYMBOLS = {
     "adk_debug_flags": (C.c_int, [C.POINTER(_i32)]),
     "adk_set_conv_cfg": (C.c_int, [_i32]),
     "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
+    "adk_causal_conv_describe": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, C.c_char_p, _i32]),
     "adk_packed_weight_floats": (C.c_int64, [_i32, _i32, _i32]),
     "adk_pack_weights_mfma": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),
@@ -114,6 +115,38 @@ def check(rc, what=""):
         if rc in (-1, -2):
             raise ValueError(f"{what}: {msg} (adk error {rc})")
         raise NativeError(f"{what}: {msg} (adk error {rc})")
+
+
+FLAG_BAD_INDEX, FLAG_STREAMK_TIMEOUT, FLAG_BAD_CODE, FLAG_F16_OVERFLOW = 1, 2, 4, 8
+
+
+def device_flags():
+    """Read and clear the sticky device-side error flags (adk_debug_flags); synchronises the device(s)."""
+    v = C.c_int32(0)
+    check(lib().adk_debug_flags(C.byref(v)), "adk_debug_flags")
+    return int(v.value)
+
+
+def raise_on_device_flags(where=""):
+    """Turn a device-side failure into the exception the reference's PyTorch path would have raised (or the closest
+    one).  Called where the facade synchronises anyway (payload / waveform leaves the device, end of an utterance,
+    streamer tick); kernels never stop a launch sequence, they record the failure in a sticky word."""
+    v = device_flags()
+    if not v:
+        return
+    pre = f"{where}: " if where else ""
+    if v & FLAG_BAD_INDEX:
+        raise IndexError(pre + "index out of range in self (a code index outside the codebook reached lookup; "
+                               "F.embedding raises the same in the reference, layers/vq_module.py:160)")
+    if v & FLAG_BAD_CODE:
+        raise ValueError(pre + "an index that is not a code of its stage was packed (wire format)")
+    if v & FLAG_F16_OVERFLOW:
+        raise NativeError(pre + "a split-f16 conv produced non-finite values: an operand beyond the f16 range "
+                                "(|v| > 65504) or non-finite input; results since the last check are invalid")
+    if v & FLAG_STREAMK_TIMEOUT:
+        raise NativeError(pre + "a stream-K conv workgroup timed out waiting for a partial tile; results since the "
+                                "last check are invalid")
+    raise NativeError(pre + f"device error flags {v}")
 
 
 def current_stream(device):

@@ -201,6 +201,7 @@ class TestMain:
                 zq = self.encode(x)
                 y = self.decode(zq)
                 y = y.squeeze(1).transpose(1, 0).cpu().numpy()                 # T x C
+                native.raise_on_device_flags(f"utterance {utt_id}")           # device-side failures -> exceptions
                 rtf = (time.time() - start) / (len(y) / self.decoder_config["sampling_rate"])
                 total_rtf += rtf
                 write_wav_pcm16(os.path.join(self.outdir, f"{utt_id}_output.wav"), y, self.decoder_config["sampling_rate"])
@@ -274,7 +275,9 @@ class StatisticMain:
             self.analyzer.configure(1, self.max_frames)
         self.analyzer.reset_buffer()
         zq = self.analyzer.quantizer_forward(self.analyzer.encode(x))
-        return zq.squeeze(0).transpose(1, 0).cpu().numpy()   # (T', C)
+        out = zq.squeeze(0).transpose(1, 0).cpu().numpy()    # (T', C)
+        native.raise_on_device_flags("StatisticMain.audio_analysis")
+        return out
 
     def run(self):
         try:

@@ -210,10 +210,17 @@ class AudioCodecStreamer(abc.ABC):
                         q.queue.clear()
                 self._ledger.flush()
         y = y.squeeze(0).detach().cpu()
+        if self._ledger.blocks % 16 == 0:                          # the copy above synchronised: a cheap place to surface
+            self._check_device()                                   # device-side failures as exceptions (native.py)
         self._ledger.blocks += 1
         if self._sinks["out"] is not None:
             self._sinks["out"].push(y)
         return y.transpose(1, 0).contiguous().numpy()
+
+    def _check_device(self):
+        if str(self.tx_device).startswith("cuda") or str(self.rx_device).startswith("cuda"):
+            from . import native
+            native.raise_on_device_flags("AudioCodecStreamer")
 
     def enable_filedump(self, input_stream_file: str = None, output_stream_file: str = None):
         if input_stream_file is None and output_stream_file is None:

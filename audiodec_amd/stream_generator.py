@@ -129,8 +129,15 @@ class _StreamBase:
         if not 0 <= b < self.num_streams:
             raise IndexError(f"stream {b} out of range 0..{self.num_streams - 1}")
         for name, prog in self._programs().items():
-            if prog is not None:
-                prog.restore_stream_state(b, self._warm.get(name) if warm else None)
+            if prog is None:
+                continue
+            if warm and name not in self._warm:
+                # configure / set_split16 / set_offline / set_stages / load_state_dict rebuild the programs and drop the
+                # captured warm-up: a silent all-zero reset here would not be the state the caller asked for
+                raise native.NativeError(
+                    f"reset_stream(warm=True): no warmed-up state captured for program '{name}' -- run initial_encoder / "
+                    "initial_decoder after the last configure()/set_*() call, or pass warm=False for the reset_buffer() state")
+            prog.restore_stream_state(b, self._warm[name] if warm else None)
 
     def _capture_warm(self, name, prog):
         self._warm[name] = prog.capture_stream_state(0)
@@ -348,10 +355,10 @@ class AutoEncoderStreamGenerator(_StreamBase):
         return zq
 
     # ---- bit-packed transport (audiodec_amd/wire.py; the reference has no wire format) ----
-    def pack(self, idx):
+    def pack(self, idx, check=True):
         """Emitted indices -> uint8 payload (B, T, n_q*bits/8): 10 bytes per frame for 8 x 1024 codes."""
         from . import wire
-        return wire.pack_codes(idx.to(self._dev()), self.size)
+        return wire.pack_codes(idx.to(self._dev()), self.size, check)
 
     def unpack(self, payload):
         from . import wire

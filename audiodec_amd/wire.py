@@ -22,8 +22,12 @@ def frame_bytes(n_q, codebook_size):
     return (n_q * code_bits(codebook_size) + 7) // 8
 
 
-def pack_codes(idx, codebook_size=1024):
-    """idx (n_q, T) or (n_q, B, T) int64 on a HIP device -> uint8 payload (B, T, frame_bytes)."""
+def pack_codes(idx, codebook_size=1024, check=True):
+    """idx (n_q, T) or (n_q, B, T) int64 on a HIP device -> uint8 payload (B, T, frame_bytes).
+
+    check=True (default) synchronises and raises ValueError if an index was not a code of its stage (the payload is
+    about to leave the device anyway); check=False leaves the failure in the sticky device flags
+    (native.raise_on_device_flags)."""
     dev = native.require_gpu(idx.device)
     if idx.dim() == 2:
         idx = idx.unsqueeze(1)
@@ -33,6 +37,8 @@ def pack_codes(idx, codebook_size=1024):
     out = torch.empty(B, T, (n_q * bits + 7) // 8, dtype=torch.uint8, device=dev)
     native.check(native.lib().adk_codes_pack(C.c_void_p(idx.data_ptr()), C.c_void_p(out.data_ptr()), B * T, n_q, bits,
                                              int(codebook_size), native.current_stream(dev)), "adk_codes_pack")
+    if check:
+        native.raise_on_device_flags("pack_codes")
     return out
 
 

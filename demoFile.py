@@ -11,6 +11,7 @@ import numpy as np
 import torch
 from scipy.io import wavfile
 
+from audiodec_amd import native
 from audiodec_amd.audiodec import AudioDec, assign_model
 
 
@@ -52,6 +53,7 @@ def main():
         codes = codec.tx_encoder.quantize(codec.tx_encoder.encode(x.to(device)))
         y = codec.decoder.decode(codec.rx_encoder.lookup(codes))[..., :x.shape[-1]]
     pcm = (y[:, 0].clamp(-1, 1).cpu().numpy().T * 32767.0).round().astype(np.int16)     # samples x channels, PCM_16
+    native.raise_on_device_flags("demoFile")               # a device-side failure (bad index, overflow, ...) is an error, not audio
     wavfile.write(args.output, rate, pcm)
     print(f"Output {args.output}!")
 

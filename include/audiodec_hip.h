@@ -14,6 +14,10 @@
  *   - return value: 0 = ADK_OK, negative = error (text via adk_last_error(), thread-local)
  *   - no hidden device allocation in step/op calls; a handle may be used by one host thread at a
  *     time, different handles concurrently (reference threading model: bin/stream.py:212-239)
+ *   - devices: every call runs on the HIP device that OWNS its buffers, whatever device the calling thread has
+ *     current (the reference's --tx_cuda / --rx_cuda put the two halves on different GPUs, demoStream.py:33-40):
+ *     a program is bound to the device of its arena at adk_program_create; op-level calls look the device up from
+ *     their output pointer; the scratch workspace and the sticky flag word are per device
  *
  * Data layout ("rings")
  *   Every stateful conv input lives in a ring of channel-last rows: ring[b][r][c], r in [0,rows),
@@ -32,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 5
+#define ADK_ABI_VERSION 6
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -54,8 +58,9 @@ int adk_abi_version(void);
  * where F.embedding would raise; bit 1: a stream-K conv workgroup gave up waiting for another workgroup's
  * partial tile -- results of that launch are invalid; bit 2: adk_codes_pack saw an index that
  * is not a code of its stage; bit 3: a split-f16 kernel produced a non-finite output -- an operand beyond the f16 range (|v| > 65504) or a
- * non-finite input; results of that launch are invalid); reading synchronises the device
- * and clears them */
+ * non-finite input; results of that launch are invalid); the value is the OR over every device the library
+ * has launched on; reading synchronises those devices and clears the words.  The Python facade turns a set bit
+ * into an exception at its synchronisation points (audiodec_amd/native.py: raise_on_device_flags) */
 int adk_debug_flags(int32_t* out);
 /* tuning hook: force the MFMA conv tile config (0..5), -1 = heuristic (also env ADK_CONV_CFG) */
 int adk_set_conv_cfg(int32_t cfg);
@@ -116,6 +121,10 @@ int adk_pack_weights_split16(const float* w, float* out, int32_t groups, int32_t
 
 int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
                     int32_t batch, int32_t t_out, int32_t impl, void* stream);
+/* name of the kernel the call above would launch (e.g. "conv_sk16<128x64>"), nothing is launched: for profiles and
+ * for tests that must know which kernel they exercised */
+int adk_causal_conv_describe(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
+                             int32_t batch, int32_t t_out, int32_t impl, char* buf, int32_t n);
 
 /*
  * Copy caller rows into a ring, optionally normalising: ring row = (src - mean) / scale.
@@ -156,7 +165,8 @@ int adk_rvq_lookup(const int64_t* idx, const float* codebook, float* zq,
  * adk_codes_frame_bytes(n_q, bits) = ceil(n_q*bits/8) byte frame; 8 x 10 bit = 10 bytes = 12.8 kbps at
  * 160 frames/s.  idx is [n_q][n_rows] int64 as emitted by adk_rvq_encode; payload is [n_rows][frame_bytes].
  * adk_codes_lookup = unpack fused into ResidualVQ.lookup (layers/vq_module.py:159-161).
- * A code >= size raises adk_debug_flags bit 2 (pack) / bit 0 (lookup, reads code 0).
+ * A code >= size raises adk_debug_flags bit 2 (pack; it is packed as code 0 so that it cannot spill into the
+ * neighbouring codes' bits) / bit 0 (lookup, reads code 0).
  */
 int32_t adk_codes_frame_bytes(int32_t n_q, int32_t bits);
 int adk_codes_pack(const int64_t* idx, uint8_t* payload, int32_t n_rows, int32_t n_q, int32_t bits, int32_t size, void* stream);

@@ -18,3 +18,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    """The HIP device of the -m gpu tests; builds the in-tree library if it is stale."""
+    import torch
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    import __graft_entry__
+    __graft_entry__.build()                  # no-op when the in-tree .so matches its sources
+    from audiodec_amd import native
+    native.lib()
+    return "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ckpt_root(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("audiodec_ckpt"))

@@ -245,6 +245,11 @@ CASES = {
     "vctk_v2_stream": ("vctk_v2", 1, [1, 2], None),
     "vctk_activate_sym_stream": ("vctk_activate_sym", 1, [1, 2], None),
     "vctk_c16h320_sym_stream": ("vctk_c16h320_sym", 1, [1, 2], None),
+    # the remaining aliases of utils/audiodec.py:109-179 (round 2)
+    "libritts_v1_stream": ("libritts_v1", 1, [2, 1], None),
+    "vctk_denoise_stream": ("vctk_denoise", 1, [1, 2], None),
+    "vctk_univ_stream": ("vctk_univ", 1, [1, 2], None),
+    "vctk_univ_sym_stream": ("vctk_univ_sym", 1, [2, 1], None),
 }
 
 

@@ -25,21 +25,6 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=False)
 
 
-@pytest.fixture(scope="module")
-def gpu():
-    assert torch.cuda.is_available(), "these tests need a HIP device"
-    import __graft_entry__
-    __graft_entry__.build()                  # no-op when the in-tree .so is newer than its sources
-    from audiodec_amd import native
-    native.lib()
-    return DEV
-
-
-@pytest.fixture(scope="module")
-def ckpt_root(tmp_path_factory):
-    return str(tmp_path_factory.mktemp("audiodec_ckpt"))
-
-
 def load_audiodec(ckpt_root, model, seed, num_streams, max_frames, split16=False):
     from audiodec_amd.audiodec import AudioDec, assign_model
     synth.write_model(ckpt_root, model, seed)
@@ -215,7 +200,8 @@ def run_hip(ad, audio, chunks):
 
 @pytest.mark.parametrize("name,max_frames", [("vctk_sym_stream", 2), ("vctk_v1_stream", 4), ("libritts_sym_file", 16),
                                              ("vctk_v2_stream", 2), ("vctk_v0_stream", 2), ("vctk_activate_sym_stream", 2),
-                                             ("vctk_c16h320_sym_stream", 2)])
+                                             ("vctk_c16h320_sym_stream", 2), ("libritts_v1_stream", 2), ("vctk_denoise_stream", 2),
+                                             ("vctk_univ_stream", 2), ("vctk_univ_sym_stream", 2)])
 @pytest.mark.parametrize("split16", [False, True], ids=["f32", "split16"])
 def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames, split16):
     g = _load(golden_dir, name)

@@ -1,0 +1,105 @@
+"""RVQ index soak: >= 1e5 nearest-code decisions on the HIP path against the reference arithmetic
+(VectorQuantize.forward_index, layers/vq_module.py:93-102; ResidualVQ.forward_index, :136-149).
+
+The emitted indices must be bit-exact for the same input.  Two things can still move a decision: (a) the latent z the
+HIP encoder produces differs from the reference's by f32 round-off (measured ~1e-6 max-abs), (b) the distance
+`(|r|^2 - (2r).E) + |E|^2` is summed in another order than the reference's sgemm.  Either can only matter where the
+reference's own best and second-best codes are closer than the perturbation, so every flip is reported with the
+reference's top-2 distance margin and must lie below a stated bound ("RVQ index soak"):
+
+    same z in (kernel arithmetic only):   margin < 2e-5
+    end to end (HIP encoder + kernel):    margin < 1e-4
+
+A report (flip list, low tail of the margin histogram) is written to gpurun_out/ when that directory exists.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiodec_amd import synth
+from test_gpu_parity import load_audiodec, DEV
+from test_oracle_golden import build_oracle_shared_warmup
+
+pytestmark = pytest.mark.gpu
+
+HOP = 300
+STREAMS, FRAMES, CHUNK = 64, 200, 8          # 64 x 200 x 8 stages = 102,400 decisions
+BOUND_SAME_Z, BOUND_END_TO_END = 2e-5, 1e-4
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _first_flips(idx, ref, margin):
+    """[(stream, frame, stage, reference margin)] for the FIRST differing stage of every frame whose codes differ
+    (later stages quantise a different residual and are not independent decisions)."""
+    bad = idx != ref
+    out = []
+    for b, t in np.argwhere(bad.any(0)):
+        q = int(np.argmax(bad[:, b, t]))
+        out.append((int(b), int(t), q, float(margin[q, b, t])))
+    return out
+
+
+def _report(name, flips, margin, extra=None):
+    tail = {f"margin<{b:g}": int((margin < b).sum()) for b in (1e-6, 1e-5, 1e-4, 1e-3, 1e-2)}
+    rep = {"case": name, "decisions": int(margin.size), "flips": len(flips),
+           "flip_list": [dict(stream=b, frame=t, stage=q, reference_margin=m) for b, t, q, m in flips],
+           "reference_margin_min": float(margin.min()), "reference_margin_low_tail": tail}
+    rep.update(extra or {})
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"soak_{name}.json"), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    return rep
+
+
+@pytest.fixture(scope="module")
+def soak_reference():
+    """The reference side, once: latents, indices and top-2 margins of 64 streams x 200 frames."""
+    audio = np.stack([synth.synth_audio(2024, s, FRAMES * HOP) for s in range(STREAMS)])
+    tx, _, _ = build_oracle_shared_warmup("vctk_v1", STREAMS, 1337)
+    zs, is_, ms = [], [], []
+    with torch.no_grad():
+        for f0 in range(0, FRAMES, CHUNK):                      # the same call sequence the HIP path is given
+            z = tx.encode(torch.from_numpy(audio[:, f0 * HOP:(f0 + CHUNK) * HOP])[:, None, :])
+            i, m = tx.quantize(z, return_margin=True)
+            zs.append(z); is_.append(i); ms.append(m)
+    return audio, torch.cat(zs, -1), torch.cat(is_, -1).numpy(), torch.cat(ms, -1).numpy()
+
+
+@pytest.mark.parametrize("split16", [False, True], ids=["f32", "split16"])
+def test_rvq_soak_end_to_end(gpu, ckpt_root, soak_reference, split16):
+    audio, oz, oi, om = soak_reference
+    ad = load_audiodec(ckpt_root, "vctk_v1", 1337, STREAMS, CHUNK, split16)
+    zs, idxs = [], []
+    with torch.no_grad():
+        for f0 in range(0, FRAMES, CHUNK):
+            x = torch.from_numpy(audio[:, f0 * HOP:(f0 + CHUNK) * HOP])[:, None, :].to(DEV)
+            z = ad.tx_encoder.encode(x)
+            idxs.append(ad.tx_encoder.quantize(z).cpu()); zs.append(z.cpu())
+    z = torch.cat(zs, -1); idx = torch.cat(idxs, -1).numpy()
+    assert idx.shape == oi.shape == (8, STREAMS, FRAMES) and idx.size >= 100_000
+    dz = float((z - oz).abs().max())
+    flips = _first_flips(idx, oi, om)
+    rep = _report("end_to_end_" + ("split16" if split16 else "f32"), flips, om, {"max_abs_dz": dz, "bound": BOUND_END_TO_END})
+    assert dz < 1e-4, dz
+    worst = max((m for *_, m in flips), default=0.0)
+    assert worst < BOUND_END_TO_END, f"{len(flips)} flips, largest reference margin {worst:.3e}: {rep['flip_list'][:5]}"
+
+
+def test_rvq_soak_same_latent(gpu, soak_reference):
+    """The reference's own z into the HIP quantiser: only the kernel's arithmetic is under test."""
+    from audiodec_amd import configs, layers
+    audio, oz, oi, om = soak_reference
+    _, enc_tag, _, _, _ = configs.alias("vctk_v1")
+    sd = synth.synth_state_dict(enc_tag, 1337)
+    rvq = layers.ResidualVQ([sd[f"quantizer.codebook.layers.{i}.embed"] for i in range(8)], device=gpu)
+    _, idx = rvq.forward_index(oz.transpose(2, 1).contiguous(), flatten_idx=True)
+    idx = idx.cpu().numpy()
+    assert idx.shape == oi.shape
+    flips = _first_flips(idx, oi, om)
+    rep = _report("same_latent", flips, om, {"bound": BOUND_SAME_Z})
+    worst = max((m for *_, m in flips), default=0.0)
+    assert worst < BOUND_SAME_Z, f"{len(flips)} flips, largest reference margin {worst:.3e}: {rep['flip_list'][:5]}"

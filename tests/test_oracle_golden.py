@@ -37,6 +37,23 @@ def build_oracle(model, batch, seed):
     return tx, rx, dec
 
 
+def widen_oracle(o, batch):
+    """Carry `batch` streams in an oracle that was warmed up with one: every stream saw the same silence, so the
+    per-layer pad buffers are replicated.  (ATen's CPU convs are not bit-invariant to the batch size -- a batch-3
+    warm-up differs from a batch-1 one by f32 round-off, ~1e-7 -- so this equals a `batch`-stream warm-up to round-off,
+    and equals `batch` separate reference instances exactly at the moment of widening; checked below on the CPU.)"""
+    o.batch = batch
+    for k in list(o.pad):
+        o.pad[k] = o.pad[k].expand(batch, -1, -1).clone()
+    return o
+
+
+def build_oracle_shared_warmup(model, batch, seed):
+    """build_oracle for many streams at the cost of ONE warm-up (the 256-stream parity tests)."""
+    tx, rx, dec = build_oracle(model, 1, seed)
+    return widen_oracle(tx, batch), rx, widen_oracle(dec, batch)
+
+
 def golden_chunks(g):
     hop = int(g["hop"])
     if int(g["one_shot_len"]) > 0:
@@ -59,7 +76,8 @@ def explain_flips(idx, ref_idx, margin, what):
 
 
 CASES = ["vctk_sym_stream", "vctk_v1_stream", "libritts_sym_file", "vctk_v0_stream", "vctk_v2_stream",
-         "vctk_activate_sym_stream", "vctk_c16h320_sym_stream"]
+         "vctk_activate_sym_stream", "vctk_c16h320_sym_stream", "libritts_v1_stream", "vctk_denoise_stream",
+         "vctk_univ_stream", "vctk_univ_sym_stream"]          # all 11 aliases of utils/audiodec.py:109-179
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -111,6 +129,20 @@ def test_oracle_layers_match_reference_fixture(golden_dir):
     assert np.abs(q.numpy() - g["rvq_q"]).max() < 1e-5
     zq = O.rvq_lookup(idx, O.rvq_codebook(embeds))
     assert np.abs(zq.numpy() - g["rvq_zq"]).max() < 1e-5
+
+
+def test_shared_warmup_equals_per_stream_warmup():
+    a = build_oracle("vctk_v1", 3, 1337)
+    b = build_oracle_shared_warmup("vctk_v1", 3, 1337)
+    for oa, ob in ((a[0], b[0]), (a[2], b[2])):
+        assert oa.pad.keys() == ob.pad.keys()
+        for k in oa.pad:
+            assert oa.pad[k].shape == ob.pad[k].shape and float((oa.pad[k] - ob.pad[k]).abs().max()) < 1e-5, k
+    x = torch.from_numpy(np.stack([synth.synth_audio(5, s, 300) for s in range(3)]))[:, None, :]
+    with torch.no_grad():
+        ia = a[0].quantize(a[0].encode(x)); ib = b[0].quantize(b[0].encode(x))
+        assert torch.equal(ia, ib)
+        assert float((a[2].decode(a[1].lookup(ia)) - b[2].decode(b[1].lookup(ib))).abs().max()) < TOL
 
 
 # ---- the reference's implied invariants, held by the oracle -------------
