@@ -71,16 +71,30 @@ static int ensure_workspace(Workspace& w) {
 }
 
 static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
+static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
+
+static bool is_split16(int impl) {
+    return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
+}
+static void read_env() {
+    if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
+    if (g_use_up < 0) { const char* e = getenv("ADK_CONV_UP16"); g_use_up = e ? atoi(e) : 1; }
+}
 
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
-    if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
+    read_env();
     const bool ok = conv_mfma_supported(a);
     if (impl == ADK_IMPL_MFMA_ROWS) {
         if (!conv_rl_supported(a)) return fail(ADK_ERR_SHAPE, "conv: rows-in-LDS kernel needs stride 1, 32/64 channels per group, w_frag");
         return launch_conv_rl(a, s);
     }
-    if (impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK) {
-        // split-f16 kernels (w_frag in the adk_pack_weights_split16 layout): rows-in-LDS when it fills the chip, else stream-K
+    if (is_split16(impl)) {
+        // split-f16 kernels (w_frag in the adk_pack_weights_split16 layout): the up-sampling streamer for its one layer shape,
+        // rows-in-LDS when it fills the chip, else stream-K
+        if (impl == ADK_IMPL_SPLIT16_UP && !conv_up16_supported(a))
+            return fail(ADK_ERR_SHAPE, "conv: the up-sampling streamer takes 2-tap transposed convs with 64 input channels and <= 96 GEMM rows");
+        if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a)))
+            return launch_conv_up16(a, s);
         if (impl == ADK_IMPL_SPLIT16_ROWS && !conv_rl16_supported(a))
             return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
         if (impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a)))
@@ -88,6 +102,7 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         if (!ok) return fail(ADK_ERR_SHAPE, "conv: split-f16 kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
+        if (impl == ADK_IMPL_SPLIT16 && conv_gk16_pick(a)) return launch_conv_gk16(a, s, ws);
         return launch_conv_sk16(a, s, ws);
     }
     const bool want_mfma = (impl == ADK_IMPL_MFMA) || (impl == ADK_IMPL_AUTO && ok && a.groups * a.cout_g >= 32);
@@ -106,10 +121,15 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
 
 // name of the kernel run_conv would launch for these arguments (profiles, tests)
 static std::string conv_kernel_name(const ConvArgs& a, int impl) {
-    if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
-    if (impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK) {
+    read_env();
+    if (is_split16(impl)) {
+        if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
+        if (impl == ADK_IMPL_SPLIT16 && conv_mfma_supported(a)) {
+            const int gk = conv_gk16_pick(a);
+            if (gk) return gk == 1 ? "conv_gk16<256x128>" : "conv_gk16<128x256>";
+        }
         return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
     }
     const bool mf = impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (impl == ADK_IMPL_MFMA || impl == ADK_IMPL_MFMA_ROWS || a.groups * a.cout_g >= 32);
@@ -237,7 +257,7 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             if (o.w_off < 0 && o.wf_off < 0) return bail(ADK_ERR_ARG, "program_create: op has no weights");
             if (o.w_off >= 0 && (o.w_off % 4 || o.w_off + wn > weights_floats)) return bail(ADK_ERR_SHAPE, "program_create: weight offset out of range");
             if (o.wf_off >= 0) {
-                const bool s16 = o.impl == ADK_IMPL_SPLIT16 || o.impl == ADK_IMPL_SPLIT16_ROWS || o.impl == ADK_IMPL_SPLIT16_SK;
+                const bool s16 = is_split16(o.impl);
                 const long long wfn = s16 ? adk_packed_weight_floats_split16(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g)
                                           : adk_packed_weight_floats(o.conv.groups, o.conv.cout_g, o.conv.taps * o.conv.cin_g);
                 if (wfn < 0 || o.wf_off % 4 || o.wf_off + wfn > weights_floats) return bail(ADK_ERR_SHAPE, "program_create: packed weight offset out of range");

@@ -4,6 +4,7 @@
 //   ring_write: torch.cat of new rows onto the state (layers/conv_layer.py:154) + HiFiGAN decode_norm
 //               (models/vocoder/HiFiGAN.py:276-279)
 #include "adk_common.h"
+#include <cstdlib>
 
 namespace adk {
 
@@ -142,6 +143,107 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_kernel(const float* __
         }
 }
 
+// ---- v2: the same arithmetic, shorter dependency chain per stage (dim == 64, size == 1024) ----
+// One thread = one code, its 64 components live in REGISTERS for the stage:
+//   * all 64 component loads of a stage are in flight at once (v1: four dependent batches of 16), and the NEXT stage's are
+//     issued as soon as the winner has handed its code over -- they land during the residual update and two barriers;
+//   * the winning thread writes q from its registers to LDS (v1: a dependent gather from global memory after the argmax);
+//   * every thread folds the 16 per-wave candidates itself (v1: RB threads + a barrier), wave rr owns row rr: it keeps r and
+//     the running sum of q' in registers and forms |r|^2 for the next stage right after the update (v1: its own phase).
+// Three barriers per stage instead of five, ~3 us per stage instead of ~11.  Per element the operations and their order are
+// v1's (ascending-d fmaf chain, the same butterfly for |r|^2, the same (value, index) merges), so the indices are the same.
+template <int RB>
+__global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v2_kernel(const float* __restrict__ z, const float* __restrict__ embed,
+                                                                    const float* __restrict__ enorm, long long* __restrict__ idx,
+                                                                    float* __restrict__ zq, int n_rows, int n_q) {
+    constexpr int D = 64, SIZE = 1024;
+    __shared__ __attribute__((aligned(16))) float r2t_sh[D][RB];   // 2*r, dim-major: one broadcast read per d for all RB rows
+    __shared__ __attribute__((aligned(16))) float q_sh[RB][D];
+    __shared__ float rn_sh[RB];
+    __shared__ float red_v[RB][RVQ_WAVES];
+    __shared__ int red_i[RB][RVQ_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * RB;
+    const bool owner = wave < RB;                          // wave rr owns row rr, lane = dimension
+    float r_reg = 0.f, qsum = 0.f;
+    float e[D];
+    auto load_codes = [&](int st) {
+        const float* Ec = embed + (size_t)st * D * SIZE + tid;
+#pragma unroll
+        for (int d = 0; d < D; ++d) e[d] = Ec[(size_t)d * SIZE];
+    };
+    load_codes(0);
+    if (owner) {
+        r_reg = (row0 + wave < n_rows) ? z[(size_t)(row0 + wave) * D + lane] : 0.f;
+        r2t_sh[lane][wave] = 2.f * r_reg;
+        float v = __fmul_rn(r_reg, r_reg);                 // flatten.pow(2).sum(1): the butterfly of v1
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+        if (lane == 0) rn_sh[wave] = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < n_q; ++st) {
+        float acc[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {                      // (2*flatten) @ embed, d ascending (vq_module.py:95)
+            if constexpr (RB == 4) {
+                const float4 r2 = *reinterpret_cast<const float4*>(&r2t_sh[d][0]);
+                acc[0] = fmaf(r2.x, e[d], acc[0]); acc[1] = fmaf(r2.y, e[d], acc[1]);
+                acc[2] = fmaf(r2.z, e[d], acc[2]); acc[3] = fmaf(r2.w, e[d], acc[3]);
+            } else if constexpr (RB == 2) {
+                const float2 r2 = *reinterpret_cast<const float2*>(&r2t_sh[d][0]);
+                acc[0] = fmaf(r2.x, e[d], acc[0]); acc[1] = fmaf(r2.y, e[d], acc[1]);
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) acc[rr] = fmaf(r2t_sh[d][rr], e[d], acc[rr]);
+            }
+        }
+        const float en = enorm[(size_t)st * SIZE + tid];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {                  // dist = (|r|^2 - 2rE) + |E|^2 ; argmax(-dist), lowest index on ties
+            float v = -__fadd_rn(__fsub_rn(rn_sh[rr], acc[rr]), en);
+            int i = tid;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float v2 = __shfl_xor(v, off, 64);
+                const int i2 = __shfl_xor(i, off, 64);
+                argmax_merge(v, i, v2, i2);
+            }
+            if (lane == 0) { red_v[rr][wave] = v; red_i[rr][wave] = i; }
+        }
+        __syncthreads();                                   // A: candidates of all waves visible
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            float v = red_v[rr][0]; int i = red_i[rr][0];
+#pragma unroll
+            for (int w = 1; w < RVQ_WAVES; ++w) argmax_merge(v, i, red_v[rr][w], red_i[rr][w]);
+            if (i == tid) {                                // the winner hands its code over from registers
+#pragma unroll
+                for (int d4 = 0; d4 < D / 4; ++d4)
+                    *reinterpret_cast<float4*>(&q_sh[rr][4 * d4]) = make_float4(e[4 * d4], e[4 * d4 + 1], e[4 * d4 + 2], e[4 * d4 + 3]);
+                if (row0 + rr < n_rows) idx[(size_t)st * n_rows + row0 + rr] = (long long)i + (long long)SIZE * st;
+            }
+        }
+        if (st + 1 < n_q) load_codes(st + 1);              // in flight during the update below
+        __syncthreads();                                   // B: q visible
+        if (owner) {                                       // straight-through + residual (vq_module.py:101-102,143-144)
+            const float q = q_sh[wave][lane];
+            const float qp = __fadd_rn(r_reg, __fsub_rn(q, r_reg));
+            r_reg = __fsub_rn(r_reg, qp);
+            qsum = __fadd_rn(qsum, qp);
+            r2t_sh[lane][wave] = 2.f * r_reg;
+            float v = __fmul_rn(r_reg, r_reg);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+            if (lane == 0) rn_sh[wave] = v;
+        }
+        __syncthreads();                                   // C: residual of the next stage visible
+    }
+    if (zq && owner && row0 + wave < n_rows) zq[(size_t)(row0 + wave) * D + lane] = qsum;
+}
+
 __global__ __launch_bounds__(256) void rvq_lookup_kernel(const long long* __restrict__ idx, const float* __restrict__ codebook,
                                                          float* __restrict__ zq, int n_rows, int n_q, int dim, int n_codes) {
     const int d4 = dim / 4;
@@ -241,6 +343,20 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
     if (n_rows == 0) return ADK_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DeviceGuard guard(device_of(z));
+    static int variant = -1;                              // ADK_RVQ_V1=1: the first-round kernel (A/B and cross-checks)
+    static int rb_env = 0;                                // ADK_RVQ_MAXROWS: largest row count the v2 kernel takes (tuning; default 512)
+    if (variant < 0) {
+        const char* e = getenv("ADK_RVQ_V1"); variant = (e && atoi(e) == 1) ? 1 : 2;
+        e = getenv("ADK_RVQ_MAXROWS"); rb_env = e ? atoi(e) : 0;
+    }
+    if (variant == 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 512)) {
+        // the latency kernel: one workgroup per row (every CU busy up to 256 rows; each workgroup streams the 2 MB of codes from
+        // L2, which is why the 4-rows-per-workgroup kernel below keeps the large row counts)
+        hipLaunchKernelGGL(rvq_encode_v2_kernel<1>, dim3(n_rows), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
+                           reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
+        ADK_HIP_CHECK(hipGetLastError());
+        return ADK_OK;
+    }
     constexpr int RB = 4;
     hipLaunchKernelGGL(rvq_encode_kernel<RB>, dim3((n_rows + RB - 1) / RB), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
                        reinterpret_cast<long long*>(idx), zq, n_rows, n_q, dim, size);

@@ -657,15 +657,19 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             ncpu = os.cpu_count() or 1
+            many = min(ncpu, 16)
             # more legs of the same measurement: the reference's per-call inspect.stack() cost emulated on top
             # of the port, and all host cores instead of the demo's 4 threads (demoFile.py:28)
             out["cpu_baseline"]["as_is_emulated"] = {k: v for k, v in cpu_baseline(6.0, 4, stack_calls=6).items() if k in ("value", "unit", "cores", "sample", "ms_per_frame")}
             out["cpu_baseline"]["as_is_emulated"]["note"] = ("the port + 6 inspect.stack() calls per frame = the reference's check_mode call sites on this path "
                                                             "(encoder.py:77,138, projector.py:53); the unmodified reference cannot run on the GPU box (no /root/reference there)")
-            out["cpu_baseline"]["all_cores"] = {k: v for k, v in cpu_baseline(6.0, ncpu).items() if k in ("value", "unit", "cores", "sample", "ms_per_frame")}
+            out["cpu_baseline"]["more_cores"] = {k: v for k, v in cpu_baseline(6.0, many).items() if k in ("value", "unit", "cores", "sample", "ms_per_frame")}
+            out["cpu_baseline"]["more_cores"]["note"] = (f"{many} of the host's {ncpu} cpus: a batch-1 frame is ~70 small convolutions, more intra-op threads do not help "
+                                                         "-- with all 256 threads of the GPU box one frame took 24.5 s (oversubscribed ATen thread pool; measured in round 2, "
+                                                         "profiles/r2_cpu_legs.md), so the all-cores leg is capped here to keep the default run bounded")
             if not args.no_cpu_cfg1:
                 out["cpu_baseline"]["config1_file_roundtrip"] = cpu_cfg1()
-                out["cpu_baseline"]["config1_file_roundtrip_all_cores"] = cpu_cfg1(threads=ncpu)
+                out["cpu_baseline"]["config1_file_roundtrip_more_cores"] = cpu_cfg1(threads=many, reps=2)
             torch.set_num_threads(4)
     # sticky device-side error flags of the HIP library (0 = clean; see adk_debug_flags in the header)
     import ctypes

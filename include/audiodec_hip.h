@@ -50,7 +50,10 @@ enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K imp
           below that of the f32 MFMA chain (profiles/r1_f16_split_probe.txt).  w_frag must then hold the
           adk_pack_weights_split16 layout.  |operand| > 65504 (-> non-finite outputs) raises device flag bit 3.
           SPLIT16 picks between the rows-in-LDS and the stream-K variant like AUTO does; the other two force one. */
-       ADK_IMPL_SPLIT16 = 4, ADK_IMPL_SPLIT16_ROWS = 5, ADK_IMPL_SPLIT16_SK = 6 };
+       ADK_IMPL_SPLIT16 = 4, ADK_IMPL_SPLIT16_ROWS = 5, ADK_IMPL_SPLIT16_SK = 6,
+       /* the streaming kernel of the last up-sampling stage (fused activation -> ConvTranspose1d 64 -> Cout, s*Cout <= 96,
+          + bias; HiFiGAN.py:285-289): SPLIT16 picks it for that layer shape, this value forces it */
+       ADK_IMPL_SPLIT16_UP = 7 };
 
 const char* adk_last_error(void);
 int adk_abi_version(void);

@@ -57,10 +57,11 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
     names = {k for _, k, _, _ in kern}
     if split16:
         # the kernels bench.py's headline number is made of -- all of them are in the programs checked here
-        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_sk16<128x64>", "conv_sk16<64x64>"} <= names, names
+        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_gk16<256x128>", "conv_gk16<128x256>", "conv_sk16<64x64>", "conv_up16<64>"} <= names, names
         rl_taps = {(k, t) for _, k, t, _ in kern if k.startswith("conv_rl16")}
-        assert {("conv_rl16<32>", 1), ("conv_rl16<32>", 7), ("conv_rl16<32>", 11), ("conv_rl16<64>", 1), ("conv_rl16<64>", 2),
+        assert {("conv_rl16<32>", 1), ("conv_rl16<32>", 7), ("conv_rl16<32>", 11), ("conv_rl16<64>", 1),
                 ("conv_rl16<64>", 7), ("conv_rl16<64>", 11)} <= rl_taps, rl_taps
+        assert dict((n, k) for n, k, _, _ in kern)["upsamples.3"] == "conv_up16<64>"           # the north-star's named kernel
         assert any(k.startswith("conv_rl16") and t == 1 and res for _, k, t, res in kern)       # 1x1 + residual in the rows kernel
     else:
         assert {"conv_rl<32>", "conv_rl<64>", "conv_sk<64x64>"} <= names, names
@@ -122,18 +123,21 @@ def test_rows_kernel_1x1_with_residual_matches_oracle(gpu, C_, T, B, bias):
 
 
 @pytest.mark.parametrize("d,with_res", [(1, False), (3, True), (5, True)])
-def test_streamk_128x64_tiles_match_oracle(gpu, d, with_res):
-    """conv_sk16<128x64>: the grouped K11 convs of vocoder stage 1 (384 = 3 x 128 channels, 25 steps per frame) at a
-    stream count where AUTO picks the 128-row tiles (>= 256 tiles), LeakyReLU in, bias, residual epilogue
-    (residual_block.py:99-105), ring wrap-around over three steps."""
+@pytest.mark.parametrize("C_,T,B,impl_name,want", [(384, 25, 224, "SPLIT16_SK", "conv_sk16<128x64>"), (384, 25, 224, "SPLIT16", "conv_gk16<128x256>"),
+                                                   (768, 5, 67, "SPLIT16", "conv_gk16<256x128>")])
+def test_deep_grouped_convs_match_oracle(gpu, d, with_res, C_, T, B, impl_name, want):
+    """The grouped K11 convs of vocoder stages 0-1 (768 = 3 x 256 channels at 5 steps per frame, 384 = 3 x 128 at 25) at
+    stream counts where the dispatch picks the wide tiles: the big-tile LDS-DMA kernel conv_gk16 (256x128 and 128x256
+    tiles) and the first-round conv_sk16<128x64>; LeakyReLU in, bias, residual epilogue (residual_block.py:99-105),
+    column counts that are not a multiple of the tile, ring wrap-around over three steps."""
     from audiodec_amd import layers, native
-    B, T, C_, K, gr = 224, 25, 384, 11, 3
+    K, gr = 11, 3
     g = torch.Generator().manual_seed(77 + d)
     w = torch.randn(C_, C_ // gr, K, generator=g) / (C_ // gr * K) ** 0.5
     b = torch.randn(C_, generator=g) * 0.1
     m = layers.CausalConv1d(C_, C_, K, 1, d, gr, True, device=gpu, batch=B, max_len=T).load(w, b)
     m.set_activation("LeakyReLU", 0.1)
-    m.impl = native.IMPL_SPLIT16                                  # AUTO among the split kernels, as the programs use it
+    m.impl = getattr(native, "IMPL_" + impl_name)                # SPLIT16 = AUTO among the split kernels, as the programs use it
     pad = torch.zeros(B, C_, (K - 1) * d)
     act = torch.nn.LeakyReLU(0.1)
     for step in range(3):
@@ -145,8 +149,39 @@ def test_streamk_128x64_tiles_match_oracle(gpu, d, with_res):
         if with_res:
             ref = ref + r
         y = m.inference(x, residual=r).cpu()
-        assert m.last_kernel == "conv_sk16<128x64>", m.last_kernel
+        assert m.last_kernel == want, m.last_kernel
         assert float((y - ref).abs().max()) < 2e-5, (step, float((y - ref).abs().max()))
+    assert native.device_flags() == 0
+
+
+@pytest.mark.parametrize("cout,s,act,B,chunks", [(32, 3, "LeakyReLU", 9, [100, 100, 37, 100]), (32, 3, None, 3, [300, 5, 129]),
+                                                 (16, 2, "ELU", 4, [64, 1, 200]), (24, 4, "LeakyReLU", 2, [50, 50])])
+def test_upsampling_streamer_matches_oracle(gpu, cout, s, act, B, chunks):
+    """conv_up16 (the north-star's named kernel: fused activation -> ConvTranspose1d(64 -> cout, K = 2s, stride s) + bias,
+    models/vocoder/HiFiGAN.py:285-289, layers/conv_layer.py:194-197): chunk lengths that are not multiples of the 32-step
+    tile, longer than one 128-step workgroup, one step, ring wrap-around; with and without the input activation (the
+    symmetric decoder has none); also against the rows-in-LDS and stream-K kernels it replaces for this layer."""
+    from audiodec_amd import layers, native
+    from oracle import audiodec_oracle as O
+    g = torch.Generator().manual_seed(31 * cout + s)
+    w = torch.randn(64, cout, 2 * s, generator=g) / (2 * 64) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    fn = {None: lambda v: v, "ELU": torch.nn.ELU(), "LeakyReLU": torch.nn.LeakyReLU(0.1)}[act]
+    mods = []
+    for impl in (native.IMPL_SPLIT16_UP, native.IMPL_SPLIT16, native.IMPL_SPLIT16_SK, native.IMPL_MFMA):
+        m = layers.CausalConvTranspose1d(64, cout, 2 * s, s, device=gpu, batch=B, max_len=max(chunks)).load(w, bias)
+        m.set_activation(act, 0.1)
+        m.impl = impl
+        mods.append(m)
+    pad = torch.zeros(B, 64, 1)
+    for step, L in enumerate(chunks):
+        x = torch.randn(B, 64, L, generator=g)
+        ref, pad = O.causal_convtr1d_inference(fn(x), pad, w, bias, s)     # the reference's state holds the ACTIVATED input
+        for m in mods:
+            y = m.inference(x).cpu()
+            if m.impl in (native.IMPL_SPLIT16_UP, native.IMPL_SPLIT16):
+                assert m.last_kernel == "conv_up16<64>", m.last_kernel
+            assert y.shape == ref.shape and float((y - ref).abs().max()) < 2e-5, (m.impl, step, float((y - ref).abs().max()))
     assert native.device_flags() == 0
 
 

@@ -70,17 +70,19 @@ def test_causal_conv1d_matches_reference_layers(gpu, golden_dir, impl):
     assert ran >= 3
 
 
-@pytest.mark.parametrize("impl", ["direct", "mfma", "split16_sk", "split16_rows"])
+@pytest.mark.parametrize("impl", ["direct", "mfma", "split16_sk", "split16_rows", "split16_up"])
 def test_causal_convtranspose1d_matches_reference_layers(gpu, golden_dir, impl):
     from audiodec_amd import layers, native
     g = _load(golden_dir, "ops")
     for n, (ci, co, s, L1, L2) in enumerate(C.CONVTS):
         if impl == "split16_rows" and (ci not in (32, 64) or (s * co) % 32):
             continue                                          # the rows-in-LDS kernel takes 32 / 64 input channels
+        if impl == "split16_up" and (ci != 64 or (s * co) % 32 or s * co > 96):
+            continue                                          # the up-sampling streamer: 64 input channels, <= 96 GEMM rows
         x1, x2, w, bias = C.convt_inputs(n)
         m = layers.CausalConvTranspose1d(ci, co, 2 * s, s, device=gpu, batch=1, max_len=64).load(w, bias)
         m.impl = {"mfma": native.IMPL_MFMA, "direct": native.IMPL_DIRECT, "split16_sk": native.IMPL_SPLIT16_SK,
-                  "split16_rows": native.IMPL_SPLIT16_ROWS}[impl]
+                  "split16_rows": native.IMPL_SPLIT16_ROWS, "split16_up": native.IMPL_SPLIT16_UP}[impl]
         y1 = m.inference(x1).cpu().numpy()
         y2 = m.inference(x2).cpu().numpy()
         assert np.abs(y1 - g[f"convT{n}_y1"]).max() < 1e-5, (n, impl)
