@@ -60,8 +60,8 @@ bool conv_rl16_preferred(const ConvArgs& a);
 int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
 bool conv_up16_supported(const ConvArgs& a);        // streaming kernel of the last up-sampling stage (64 -> s*Cout <= 96 rows, 2 taps)
 int launch_conv_up16(const ConvArgs& a, hipStream_t s);
-int conv_gk16_pick(const ConvArgs& a);              // big-tile split-f16 stream-K for the deep layers: 0 = not taken, 1 = 256x128, 2 = 128x256
-int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws);
+int conv_gk16_pick(const ConvArgs& a, bool force = false);              // big-tile split-f16 stream-K for the deep layers: 0 = not taken, 1 = 256x128, 2 = 128x256, 3 = 128x128
+int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws, bool force = false);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
 int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);

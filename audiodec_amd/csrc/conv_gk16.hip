@@ -15,6 +15,15 @@
 //     applied when a wave reads its B fragment (once per 64 output channels; the f16 matrix cores leave the VALU idle);
 //     LDS rows are 128 bytes, XOR-swizzled on the SOURCE address so that the fragment reads are bank-conflict free;
 //   * weights come in the adk_pack_weights_split16 fragment order, so their DMA is a straight lane-linear copy.
+//
+// MEASURED (round 2, tools/kbench, 256 streams, profiles/r2_gk16_experiment.md): correct (max |d| 4e-6 against the exact-f32
+// kernel, parity tests green end to end) and SLOWER than conv_sk16 on every layer -- grouped K11 256-ch 58 vs 51 us, 128-ch
+// 55-65 vs 52 us, encoder K7 47 vs 28 us.  Two reasons, both visible in the numbers: (1) the LDS-DMA path delivered ~12 GB/s per
+// CU here (3 TB/s chip-wide; MI355X_MICROARCH.md quotes 25 GB/s per loader wave) where the 64-wide kernel pulls ~27 GB/s per CU
+// through plain 16-byte loads, so a 32-deep slice takes 2.5-4 us instead of the 0.75 us the matrix cores need; (2) converting at
+// fragment-read time costs ~400 VALU instructions per slice per wave, twice the MFMA issue time.  With few tiles the serial
+// reduction of 64-128 KB partial slabs by the tile owner (22 GB/s) made it 3-6x slower still (first version: 141 vs 29 us).
+// It therefore stays OPT-IN (ADK_CONV_GK16=1 / ADK_IMPL_SPLIT16_GK) as the record of that experiment and a test bed.
 #include "adk_common.h"
 #include <type_traits>
 #include <cstdlib>
@@ -110,7 +119,7 @@ __device__ __forceinline__ void gk_epilogue(const ConvArgs& a, const f32x16 (&ac
 
 // WM x WN waves, each a 64 x 64 output block.  One iteration = one 32-deep K slice of one tile.
 template <int WM, int WN, int ACT>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_gk16_kernel(ConvArgs a, GkArgs gk) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int XB = BN * 128;                      // bytes of the activation part of a stage: BN columns x 32 floats
@@ -327,7 +336,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_gk16_kernel(
                 // head of this range: the tile belongs to the workgroup holding its first slice.  Publish the raw partial sums:
                 // write-through (sc1) 16-byte stores, every wave drains, barrier, one relaxed agent-scope flag (guide G16 R1)
                 const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(gk.ws, 0, gk.ws_bytes, 0x00020000);
-                const unsigned wbase = ((unsigned)r * (unsigned)NT + (unsigned)tid) * 256u;
+                // slab layout [range][16 pieces][thread][16 B]: every store / load instruction of a wave is one contiguous KiB
+                const unsigned wbase = (unsigned)r * (unsigned)(NT * 256) + (unsigned)tid * 16u;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_gk16_kernel(
                             u32x4g v;
                             v.x = __float_as_uint(am[i][j][4 * e4]); v.y = __float_as_uint(am[i][j][4 * e4 + 1]);
                             v.z = __float_as_uint(am[i][j][4 * e4 + 2]); v.w = __float_as_uint(am[i][j][4 * e4 + 3]);
-                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)((i * 2 + j) * 64 + e4 * 16), 0, 16 /* sc1 */);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)(((i * 2 + j) * 4 + e4) * (NT * 16)), 0, 16 /* sc1 */);
                         }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -362,14 +372,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_gk16_kernel(
                     __syncthreads();
                     for (int rr = r + 1; rr < rr_end; ++rr) {
                         if (gk_u0(rr + 1, gk) <= gk_u0(rr, gk)) continue;
-                        const float* wsp = gk.ws + ((size_t)rr * NT + tid) * 64;
+                        const float* wsp = gk.ws + (size_t)rr * (NT * 64) + (size_t)tid * 4;
+                        float4 pv[16];                             // all 16 pieces of this contributor in flight, then added in order
+#pragma unroll
+                        for (int pc = 0; pc < 16; ++pc) pv[pc] = *reinterpret_cast<const float4*>(wsp + (size_t)pc * (NT * 4));
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
 #pragma unroll
                                 for (int e4 = 0; e4 < 4; ++e4) {
-                                    const float4 v = *reinterpret_cast<const float4*>(wsp + (i * 2 + j) * 16 + 4 * e4);
+                                    const float4 v = pv[(i * 2 + j) * 4 + e4];
                                     am[i][j][4 * e4] += v.x; am[i][j][4 * e4 + 1] += v.y; am[i][j][4 * e4 + 2] += v.z; am[i][j][4 * e4 + 3] += v.w;
                                 }
                     }
@@ -393,7 +406,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void conv_gk16_kernel(
     if (bad) atomicOr(gk.err, 8);
 }
 
-int g_gk_enable = -1;       // ADK_CONV_GK16=0: keep the first-round 64-wide stream-K kernel for every layer (A/B)
+int g_gk_enable = -1;       // ADK_CONV_GK16=1: AUTO takes this kernel where its heuristic says so; 2|3|4: force 256x128 | 128x256 | 128x128.
+                            // Default 0: measured slower than the 64-wide stream-K kernel on every layer of the path (see the header)
 
 template <int WM, int WN>
 int launch_gk(const ConvArgs& a, hipStream_t s, Workspace& ws) {
@@ -413,6 +427,10 @@ int launch_gk(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     long long G = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, 256) : 256;
     const long long by_units = (gk.total + 1) / 2;
     if (G > by_units) G = (by_units + 7) / 8 * 8;
+    static int max_split = -1;                                   // ADK_GK16_SPLIT: most workgroups sharing one tile (default 4)
+    if (max_split < 0) { const char* e = getenv("ADK_GK16_SPLIT"); max_split = (e && atoi(e) > 0) ? atoi(e) : 4; }
+    if (G > tiles * max_split) G = (tiles * max_split + 7) / 8 * 8;
+    if (G > 256) G = 256;
     gk.G = (int)G;
     const size_t part_bytes = (size_t)gk.G * NT * 64 * sizeof(float);
     if (!ws.ptr || part_bytes > ws.flags_offset || ws.flags_offset + (size_t)gk.G * sizeof(unsigned) > ws.bytes)
@@ -445,26 +463,32 @@ int launch_gk(const ConvArgs& a, hipStream_t s, Workspace& ws) {
 }
 }  // namespace
 
-// 0: not taken; 1: 256 x 128 tiles; 2: 128 x 256 tiles
-int conv_gk16_pick(const ConvArgs& a) {
-    if (g_gk_enable < 0) { const char* e = getenv("ADK_CONV_GK16"); g_gk_enable = e ? atoi(e) : 1; }
-    if (!g_gk_enable || !conv_mfma_supported(a)) return 0;
+// 0: not taken; 1: 256 x 128 tiles; 2: 128 x 256 tiles; 3: 128 x 128 tiles (4 waves; the default shape)
+int conv_gk16_pick(const ConvArgs& a, bool force) {
+    if (g_gk_enable < 0) { const char* e = getenv("ADK_CONV_GK16"); g_gk_enable = e ? atoi(e) : 0; }
+    if ((!g_gk_enable && !force) || !conv_mfma_supported(a)) return 0;
     if ((unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull >= 0xf0000000ull) return 0;      // 32-bit byte offsets inside the arena view
     if (a.cout_g < 128) return 0;                                     // narrow layers keep the 64-row tiles
-    // enough work for the big tiles to pay: at least 256 (tile, slice) units -- smaller launches stay on the 64-wide tiles,
-    // whose K split reaches more CUs
-    const int forced = g_gk_enable >= 2 ? g_gk_enable - 1 : 0;       // ADK_CONV_GK16=2|3: force a shape (tuning)
-    const int shape = forced ? forced : (a.cout_g >= 256 ? 1 : 2);
-    const long long bm = shape == 1 ? 256 : 128, bn = shape == 1 ? 128 : 256;
-    const long long units = ((a.cout_g + bm - 1) / bm) * ((a.n_total + bn - 1) / bn) * a.groups * (a.ktot / GK_KS);
-    if (units < 256) return 0;
+    const int forced = g_gk_enable >= 2 ? g_gk_enable - 1 : 0;       // ADK_CONV_GK16=2|3|4: force a shape (tuning)
+    const int shape = forced ? forced : 3;
+    const long long bm = shape == 1 ? 256 : 128, bn = shape == 2 ? 256 : 128;
+    const long long tiles = ((a.cout_g + bm - 1) / bm) * ((a.n_total + bn - 1) / bn) * a.groups;
+    // The partial sums of a tile cut by a range boundary travel through memory (64 KB per cut of a 128 x 128 tile) and the
+    // owner adds them one contributor after the other: big tiles pay when there are enough of them that a tile is shared by
+    // few workgroups (measured: a launch with 10-30 tiles over 256 workgroups spends most of its time in that reduction) and
+    // K is long enough to amortise the prologue.  Everything else stays on the 64-wide tiles.
+    if (!forced && !force && (tiles < 48 || a.ktot < 256)) return 0;
     return shape;
 }
 
-int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
+int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws, bool force) {
     if (a.n_total == 0) return ADK_OK;
     (void)conv_mfma_workspace_bytes(nullptr);
-    return conv_gk16_pick(a) == 1 ? launch_gk<4, 2>(a, s, ws) : launch_gk<2, 4>(a, s, ws);
+    const int shape = conv_gk16_pick(a, force);
+    if (!shape) return fail(ADK_ERR_SHAPE, "conv: the big-tile kernel needs cin_g % 32 == 0, >= 128 output channels per group, 16-byte aligned rows");
+    if (shape == 1) return launch_gk<4, 2>(a, s, ws);
+    if (shape == 2) return launch_gk<2, 4>(a, s, ws);
+    return launch_gk<2, 2>(a, s, ws);
 }
 
 }  // namespace adk

@@ -88,8 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_up16_kernel(ConvArgs a, UpArgs u)
     if (!live) return;
 
     f16x8u bh[UP_KSTEPS], bl[UP_KSTEPS];
-#pragma unroll
-    for (int s = 0; s < UP_KSTEPS; ++s) {
+    auto convert = [&](int s) {
         const float x[8] = {xr[s][0].x, xr[s][0].y, xr[s][0].z, xr[s][0].w, xr[s][1].x, xr[s][1].y, xr[s][1].z, xr[s][1].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -98,12 +97,13 @@ __global__ __launch_bounds__(256, 2) void conv_up16_kernel(ConvArgs a, UpArgs u)
             bh[s][e] = h;
             bl[s][e] = (_Float16)((v - (float)h) * kUpLoScale);
         }
-    }
+    };
 
     float* outb = a.out + (size_t)b * a.out_rows * a.out_ch + a.out_choff;
     int orow0 = a.out_cursor + t * a.up;
     orow0 %= a.out_rows;
     bool bad = false;
+    convert(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         f32x16 am, ac;
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_up16_kernel(ConvArgs a, UpArgs u)
             const f16x8u Ah = *reinterpret_cast<const f16x8u*>(wp + s * 2048);
             const f16x8u Al = *reinterpret_cast<const f16x8u*>(wp + s * 2048 + 1024);
             am = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bh[s], am, 0, 0, 0);
+            if (mt == 0 && s + 1 < UP_KSTEPS) convert(s + 1);       // the split of the next chunk issues under this chunk's MFMAs
             ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bl[s], ac, 0, 0, 0);
             ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh[s], ac, 0, 0, 0);
         }

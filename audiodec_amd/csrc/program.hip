@@ -74,7 +74,8 @@ static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel
 static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
 
 static bool is_split16(int impl) {
-    return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
+    return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP ||
+           impl == ADK_IMPL_SPLIT16_GK;
 }
 static void read_env() {
     if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
@@ -102,6 +103,7 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         if (!ok) return fail(ADK_ERR_SHAPE, "conv: split-f16 kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
+        if (impl == ADK_IMPL_SPLIT16_GK) return launch_conv_gk16(a, s, ws, true);
         if (impl == ADK_IMPL_SPLIT16 && conv_gk16_pick(a)) return launch_conv_gk16(a, s, ws);
         return launch_conv_sk16(a, s, ws);
     }
@@ -126,9 +128,9 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
-        if (impl == ADK_IMPL_SPLIT16 && conv_mfma_supported(a)) {
-            const int gk = conv_gk16_pick(a);
-            if (gk) return gk == 1 ? "conv_gk16<256x128>" : "conv_gk16<128x256>";
+        if ((impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_GK) && conv_mfma_supported(a)) {
+            const int gk = conv_gk16_pick(a, impl == ADK_IMPL_SPLIT16_GK);
+            if (gk) return gk == 1 ? "conv_gk16<256x128>" : (gk == 2 ? "conv_gk16<128x256>" : "conv_gk16<128x128>");
         }
         return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
     }

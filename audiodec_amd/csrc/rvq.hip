@@ -344,14 +344,15 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
     hipStream_t s = static_cast<hipStream_t>(stream);
     DeviceGuard guard(device_of(z));
     static int variant = -1;                              // ADK_RVQ_V1=1: the first-round kernel (A/B and cross-checks)
-    static int rb_env = 0;                                // ADK_RVQ_MAXROWS: largest row count the v2 kernel takes (tuning; default 512)
+    static int rb_env = 0;                                // ADK_RVQ_MAXROWS: largest row count the v2 kernel takes (tuning; default 256)
     if (variant < 0) {
         const char* e = getenv("ADK_RVQ_V1"); variant = (e && atoi(e) == 1) ? 1 : 2;
         e = getenv("ADK_RVQ_MAXROWS"); rb_env = e ? atoi(e) : 0;
     }
-    if (variant == 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 512)) {
-        // the latency kernel: one workgroup per row (every CU busy up to 256 rows; each workgroup streams the 2 MB of codes from
-        // L2, which is why the 4-rows-per-workgroup kernel below keeps the large row counts)
+    if (variant == 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 256)) {
+        // the latency kernel: one workgroup per row -- one dispatch round up to 256 rows (measured 37 us for 1..32 rows, 43 us
+        // for 256, against 77-78 us of the first-round kernel; at 512 rows = two rounds it only ties, 80 vs 79 us, because each
+        // workgroup streams the 2 MB of codes from L2, so the 4-rows-per-workgroup kernel below keeps the large row counts)
         hipLaunchKernelGGL(rvq_encode_v2_kernel<1>, dim3(n_rows), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
                            reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
         ADK_HIP_CHECK(hipGetLastError());

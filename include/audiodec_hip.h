@@ -53,7 +53,9 @@ enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K imp
        ADK_IMPL_SPLIT16 = 4, ADK_IMPL_SPLIT16_ROWS = 5, ADK_IMPL_SPLIT16_SK = 6,
        /* the streaming kernel of the last up-sampling stage (fused activation -> ConvTranspose1d 64 -> Cout, s*Cout <= 96,
           + bias; HiFiGAN.py:285-289): SPLIT16 picks it for that layer shape, this value forces it */
-       ADK_IMPL_SPLIT16_UP = 7 };
+       ADK_IMPL_SPLIT16_UP = 7,
+       /* the opt-in big-tile LDS-DMA stream-K kernel (csrc/conv_gk16.hip; measured slower than SPLIT16_SK, kept as an experiment) */
+       ADK_IMPL_SPLIT16_GK = 8 };
 
 const char* adk_last_error(void);
 int adk_abi_version(void);

@@ -57,7 +57,7 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
     names = {k for _, k, _, _ in kern}
     if split16:
         # the kernels bench.py's headline number is made of -- all of them are in the programs checked here
-        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_gk16<256x128>", "conv_gk16<128x256>", "conv_sk16<64x64>", "conv_up16<64>"} <= names, names
+        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_sk16<128x64>", "conv_sk16<64x64>", "conv_up16<64>"} <= names, names
         rl_taps = {(k, t) for _, k, t, _ in kern if k.startswith("conv_rl16")}
         assert {("conv_rl16<32>", 1), ("conv_rl16<32>", 7), ("conv_rl16<32>", 11), ("conv_rl16<64>", 1),
                 ("conv_rl16<64>", 7), ("conv_rl16<64>", 11)} <= rl_taps, rl_taps
@@ -123,12 +123,12 @@ def test_rows_kernel_1x1_with_residual_matches_oracle(gpu, C_, T, B, bias):
 
 
 @pytest.mark.parametrize("d,with_res", [(1, False), (3, True), (5, True)])
-@pytest.mark.parametrize("C_,T,B,impl_name,want", [(384, 25, 224, "SPLIT16_SK", "conv_sk16<128x64>"), (384, 25, 224, "SPLIT16", "conv_gk16<128x256>"),
-                                                   (768, 5, 67, "SPLIT16", "conv_gk16<256x128>")])
+@pytest.mark.parametrize("C_,T,B,impl_name,want", [(384, 25, 224, "SPLIT16", "conv_sk16<128x64>"), (384, 25, 224, "SPLIT16_GK", "conv_gk16<128x128>"),
+                                                   (768, 5, 67, "SPLIT16_GK", "conv_gk16<128x128>"), (768, 5, 67, "SPLIT16", "conv_sk16<64x64>")])
 def test_deep_grouped_convs_match_oracle(gpu, d, with_res, C_, T, B, impl_name, want):
     """The grouped K11 convs of vocoder stages 0-1 (768 = 3 x 256 channels at 5 steps per frame, 384 = 3 x 128 at 25) at
-    stream counts where the dispatch picks the wide tiles: the big-tile LDS-DMA kernel conv_gk16 (256x128 and 128x256
-    tiles) and the first-round conv_sk16<128x64>; LeakyReLU in, bias, residual epilogue (residual_block.py:99-105),
+    stream counts where the dispatch picks the 128-row stream-K tiles (conv_sk16<128x64>), plus the opt-in big-tile LDS-DMA
+    kernel conv_gk16 on the same shapes; LeakyReLU in, bias, residual epilogue (residual_block.py:99-105),
     column counts that are not a multiple of the tile, ring wrap-around over three steps."""
     from audiodec_amd import layers, native
     K, gr = 11, 3
