@@ -209,6 +209,13 @@ struct adk_program {
     bool fresh = true;              // no step since create / reset (ADK_OP_HIST_REPLICATE runs only then)
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
     std::vector<float> last_ms;
+    // HIP-graph replay of the steady state (adk_program_set_graph): one captured graph per cursor phase
+    bool graph = false;
+    int period = 0;                 // cursor states of full-size steps repeat with this period (0: no usable period)
+    int g_lo = 0, g_hi = 0;         // ops [g_lo, g_hi) are captured; the ops touching caller buffers at either end stay eager
+    std::vector<char> seen;         // phase was run eagerly once (kernel attributes, symbol addresses are set up)
+    std::vector<hipGraphExec_t> gexec;
+    long long replays = 0, captures = 0;
 };
 
 extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const adk_ring_desc* rings, int32_t n_rings,
@@ -297,6 +304,7 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
 extern "C" void adk_program_destroy(adk_program* p) {
     if (!p) return;
     DeviceGuard guard(p->device);
+    for (hipGraphExec_t g : p->gexec) if (g) (void)hipGraphExecDestroy(g);
     if (p->ws.ptr) (void)hipFree(p->ws.ptr);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
@@ -315,6 +323,117 @@ static adk_ring_view view_of(const adk_program* p, int id, int frames, void* con
     return v;
 }
 
+// one op of the launch sequence on stream s
+static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream_t s) {
+    const adk_op_desc& o = p->ops[i];
+    int rc = ADK_OK;
+    if (o.kind == ADK_OP_CONV) {
+        adk_conv_desc d = o.conv;
+        d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
+        d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;
+        d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
+        adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
+        adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
+        adk_ring_view res; memset(&res, 0, sizeof(res));
+        if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
+        ConvArgs a;
+        rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+        if (rc == ADK_OK) rc = run_conv(a, o.impl, s, p->ws);
+    } else if (o.kind == ADK_OP_MEAN) {
+        RingMeanArgs m;
+        memset(&m, 0, sizeof(m));
+        adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
+        m.out = out.base; m.out_rows = out.rows; m.out_cursor = out.cursor;
+        m.n = o.n_mean; m.channels = out.channels; m.batch = p->batch; m.t = frames * p->rings[o.out_ring].rate;
+        for (int k = 0; k < o.n_mean; ++k) {
+            adk_ring_view sv = view_of(p, o.mean_rings[k], frames, ext, 0);
+            m.src[k] = sv.base; m.src_rows[k] = sv.rows; m.src_cursor[k] = sv.cursor;
+        }
+        rc = launch_ring_mean(m, s);
+    } else if (o.kind == ADK_OP_HIST_REPLICATE) {
+        if (p->fresh) {
+            adk_ring_view v = view_of(p, o.in_ring, frames, ext, 0);
+            rc = launch_hist_replicate(v.base, v.rows, v.channels, v.cursor, p->rings[o.in_ring].hist, p->batch, s);
+        }
+    } else {
+        adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
+        const float* mean = o.mean_off >= 0 ? p->weights + o.mean_off : nullptr;
+        const float* scale = o.scale_off >= 0 ? p->weights + o.scale_off : nullptr;
+        rc = adk_ring_write(static_cast<const float*>(ext[o.ext_src]), out, mean, scale, p->batch,
+                            frames * p->rings[o.out_ring].rate, s);
+    }
+    if (rc != ADK_OK) g_err = "op " + std::to_string(i) + ": " + g_err;
+    return rc;
+}
+
+static bool op_touches_ext(const adk_program* p, const adk_op_desc& o) {
+    auto ext_ring = [&](int id) { return id >= 0 && p->rings[id].external >= 0; };
+    if (o.kind == ADK_OP_RING_WRITE) return true;
+    if (o.kind == ADK_OP_MEAN) {
+        for (int k = 0; k < o.n_mean; ++k) if (ext_ring(o.mean_rings[k])) return true;
+        return ext_ring(o.out_ring);
+    }
+    return ext_ring(o.in_ring) || ext_ring(o.out_ring) || ext_ring(o.res_ring);
+}
+
+// Phase of the cursor state among the states full-size steps cycle through, or -1 (a short step, a restored snapshot from
+// another schedule ...): ring i of a program that has only ever taken max_frames-sized steps sits at (k * adv_i) mod rows_i.
+static int graph_phase(const adk_program* p) {
+    for (int k = 0; k < p->period; ++k) {
+        bool ok = true;
+        for (size_t i = 0; i < p->rings.size() && ok; ++i) {
+            if (p->rings[i].external >= 0) continue;
+            const long long adv = (long long)p->max_frames * p->rings[i].rate;
+            ok = p->cursor[i] == (int32_t)((k * adv) % p->rows[i]);
+        }
+        if (ok) return k;
+    }
+    return -1;
+}
+
+static void drop_graphs(adk_program* p) {
+    for (hipGraphExec_t g : p->gexec) if (g) (void)hipGraphExecDestroy(g);
+    p->gexec.assign(p->period > 0 ? p->period : 0, nullptr);
+    p->seen.assign(p->period > 0 ? p->period : 0, 0);
+}
+
+extern "C" int adk_program_set_graph(adk_program* p, int32_t enabled) {
+    if (!p) return fail(ADK_ERR_ARG, "program_set_graph: null program");
+    if (!enabled) { p->graph = false; return ADK_OK; }
+    // period of the cursor states under full-size steps = lcm_i rows_i / gcd(rows_i, adv_i); it is small only when the caller
+    // sized the rings for it (history rounded up so that rows_i is a small multiple of adv_i: audiodec_amd/program.py)
+    long long period = 1;
+    auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
+    for (size_t i = 0; i < p->rings.size(); ++i) {
+        if (p->rings[i].external >= 0) continue;
+        const long long adv = (long long)p->max_frames * p->rings[i].rate, rows = p->rows[i];
+        const long long pi = rows / gcd(rows, adv % rows == 0 ? rows : adv % rows);
+        period = period / gcd(period, pi) * pi;
+        if (period > 64) return fail(ADK_ERR_STATE, "program_set_graph: the ring cursors have no short period (size the rings as multiples of the step)");
+    }
+    // the ops touching caller buffers (first ring_write, last conv) stay eager: their pointers change from call to call
+    int lo = 0, hi = (int)p->ops.size();
+    while (lo < hi && op_touches_ext(p, p->ops[lo])) ++lo;
+    while (hi > lo && op_touches_ext(p, p->ops[hi - 1])) --hi;
+    for (int i = lo; i < hi; ++i)
+        if (op_touches_ext(p, p->ops[i]) || p->ops[i].kind == ADK_OP_HIST_REPLICATE)
+            return fail(ADK_ERR_STATE, "program_set_graph: an op in the middle of the sequence uses a caller buffer (or the offline history replicate)");
+    if (hi - lo < 2) return fail(ADK_ERR_STATE, "program_set_graph: nothing to capture");
+    DeviceGuard guard(p->device);
+    p->period = (int)period; p->g_lo = lo; p->g_hi = hi;
+    drop_graphs(p);
+    p->graph = true;
+    return ADK_OK;
+}
+
+extern "C" int adk_program_graph_stats(const adk_program* p, int64_t* replays, int64_t* captures, int32_t* period) {
+    if (!p) return fail(ADK_ERR_ARG, "program_graph_stats: null program");
+    if (replays) *replays = p->replays;
+    if (captures) *captures = p->captures;
+    if (period) *period = p->graph ? p->period : 0;
+    return ADK_OK;
+}
+
 extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream) {
     if (!p) return fail(ADK_ERR_ARG, "program_step: null program");
     if (frames <= 0 || frames > p->max_frames) return fail(ADK_ERR_SHAPE, "program_step: frames must be in [1, max_frames]");
@@ -329,50 +448,42 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
         p->ev.resize(n_ops + 1);
         for (auto& e : p->ev) ADK_HIP_CHECK(hipEventCreate(&e));
     }
+    // HIP-graph replay: full-size steps of a warmed-up program in a known cursor phase (see adk_program_set_graph)
+    const int phase = (p->graph && !p->profiling && !p->fresh && frames == p->max_frames) ? graph_phase(p) : -1;
+    const bool replay = phase >= 0 && p->seen[phase];
     if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[0], s));
     for (int i = 0; i < n_ops; ++i) {
-        const adk_op_desc& o = p->ops[i];
-        if (o.kind == ADK_OP_CONV) {
-            adk_conv_desc d = o.conv;
-            d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
-            d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;
-            d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
-            adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
-            adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
-            adk_ring_view res; memset(&res, 0, sizeof(res));
-            if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
-            ConvArgs a;
-            int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
-            if (rc == ADK_OK) rc = run_conv(a, o.impl, s, p->ws);
-            if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
-        } else if (o.kind == ADK_OP_MEAN) {
-            RingMeanArgs m;
-            memset(&m, 0, sizeof(m));
-            adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
-            m.out = out.base; m.out_rows = out.rows; m.out_cursor = out.cursor;
-            m.n = o.n_mean; m.channels = out.channels; m.batch = p->batch; m.t = frames * p->rings[o.out_ring].rate;
-            for (int k = 0; k < o.n_mean; ++k) {
-                adk_ring_view sv = view_of(p, o.mean_rings[k], frames, ext, 0);
-                m.src[k] = sv.base; m.src_rows[k] = sv.rows; m.src_cursor[k] = sv.cursor;
+        if (replay && i == p->g_lo) {
+            if (!p->gexec[phase]) {
+                // capture ops [g_lo, g_hi) once for this phase.  The stream-K publish flags carry per-launch epochs, which are
+                // frozen in a captured launch: the flags are zeroed by a memset node at the head of the graph instead (a stale
+                // flag of the previous replay would otherwise pass for this replay's publish).
+                hipGraph_t g = nullptr;
+                ADK_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int rc = ADK_OK;
+                hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(p->ws.ptr) + p->ws.flags_offset, 0, p->ws.bytes - p->ws.flags_offset, s);
+                if (e != hipSuccess) rc = fail(ADK_ERR_HIP, std::string("graph capture: memset: ") + hipGetErrorString(e));
+                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK; ++k) rc = run_op(p, k, frames, ext, s);
+                e = hipStreamEndCapture(s, &g);
+                if (rc != ADK_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+                if (e != hipSuccess || !g) return fail(ADK_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+                hipGraphExec_t ge = nullptr;
+                e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) return fail(ADK_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+                p->gexec[phase] = ge;
+                ++p->captures;
             }
-            int rc = launch_ring_mean(m, s);
-            if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
-        } else if (o.kind == ADK_OP_HIST_REPLICATE) {
-            if (p->fresh) {
-                adk_ring_view v = view_of(p, o.in_ring, frames, ext, 0);
-                int rc = launch_hist_replicate(v.base, v.rows, v.channels, v.cursor, p->rings[o.in_ring].hist, p->batch, s);
-                if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
-            }
-        } else {
-            adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
-            const float* mean = o.mean_off >= 0 ? p->weights + o.mean_off : nullptr;
-            const float* scale = o.scale_off >= 0 ? p->weights + o.scale_off : nullptr;
-            int rc = adk_ring_write(static_cast<const float*>(ext[o.ext_src]), out, mean, scale, p->batch,
-                                    frames * p->rings[o.out_ring].rate, stream);
-            if (rc != ADK_OK) { g_err = "op " + std::to_string(i) + ": " + g_err; return rc; }
+            ADK_HIP_CHECK(hipGraphLaunch(p->gexec[phase], s));
+            ++p->replays;
+            i = p->g_hi - 1;
+            continue;
         }
+        int rc = run_op(p, i, frames, ext, s);
+        if (rc != ADK_OK) return rc;
         if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[i + 1], s));
     }
+    if (phase >= 0) p->seen[phase] = 1;
     for (size_t i = 0; i < p->rings.size(); ++i)
         if (p->rings[i].external < 0)
             p->cursor[i] = (int32_t)(((long long)p->cursor[i] + (long long)frames * p->rings[i].rate) % p->rows[i]);
@@ -437,6 +548,10 @@ extern "C" int adk_program_set_cursors(adk_program* p, const int32_t* cursors, i
 extern "C" int adk_program_set_workgroups(adk_program* p, int32_t workgroups) {
     if (!p) return fail(ADK_ERR_ARG, "program_set_workgroups: null program");
     if (workgroups < 0 || (workgroups > 0 && workgroups < 8)) return fail(ADK_ERR_SHAPE, "program_set_workgroups: 0 (whole chip) or >= 8");
+    if (p->ws.workgroups != workgroups / 8 * 8) {
+        DeviceGuard guard(p->device);
+        drop_graphs(p);                       // the captured launches baked the old share into their grids
+    }
     p->ws.workgroups = workgroups / 8 * 8;
     return ADK_OK;
 }

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -75,6 +75,8 @@ SYMBOLS = {
     "adk_program_set_profiling": (C.c_int, [_vp, _i32]),
     "adk_program_set_workgroups": (C.c_int, [_vp, _i32]),
     "adk_program_last_op_ms": (C.c_int, [_vp, C.POINTER(C.c_float), _i32]),
+    "adk_program_set_graph": (C.c_int, [_vp, _i32]),
+    "adk_program_graph_stats": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
 }
 
 _lib = None

@@ -416,13 +416,31 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
 # ---------------------------------------------------------------------------------------------
 # runtime wrapper
 # ---------------------------------------------------------------------------------------------
+_NICE_PERIODS = (1, 2, 3, 4, 6, 12, 24, 48)
+
+
+def graph_ring_hist(hist, rate, max_frames):
+    """History a ring must keep so that its cursor returns to the same row after a SMALL number of full-size steps: the ring
+    length hist + max_frames*rate becomes a multiple P * (max_frames*rate) with P from _NICE_PERIODS (all divide 48, so the
+    periods of all rings of a program have a small common multiple).  That is what lets adk_program_set_graph capture one
+    launch sequence per cursor phase: ring cursors are kernel arguments."""
+    adv = max_frames * rate
+    need = -(-(hist + adv) // adv)
+    p = next((q for q in _NICE_PERIODS if q >= need), need)
+    return (p - 1) * adv
+
+
 class HipProgram:
     """One model half on one HIP device for `batch` streams (C++ adk_program + arena + weights)."""
 
-    def __init__(self, builder, batch, max_frames, device):
+    def __init__(self, builder, batch, max_frames, device, graph=False):
         self.dev = native.require_gpu(device)
         self.lib = native.lib()
         self.batch, self.max_frames = int(batch), int(max_frames)
+        if graph:
+            for r in builder.rings:
+                if r["external"] < 0:
+                    r["hist"] = graph_ring_hist(r["hist"], r["rate"], self.max_frames)
         self.op_names = list(builder.op_names)
         self.flops_per_frame = builder.flops_per_frame
         self.n_ops, self.n_rings = len(builder.ops), len(builder.rings)
@@ -452,6 +470,11 @@ class HipProgram:
                      "adk_program_create")
         self.h = h
         self._ext = (C.c_void_p * 8)()
+        self.graph = False
+        if graph:
+            rc = self.lib.adk_program_set_graph(self.h, 1)
+            self.graph = rc == native.ADK_OK          # no short cursor period / nothing to capture: the program stays eager
+
 
     def __del__(self):
         try:
@@ -523,6 +546,12 @@ class HipProgram:
                 v[b, rows] = 0.0
             else:
                 v[b, rows] = state[i]
+
+    def graph_stats(self):
+        """(graph replays, graphs captured, cursor period) -- (0, 0, 0) for an eager program."""
+        r, c, per = C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        native.check(self.lib.adk_program_graph_stats(self.h, C.byref(r), C.byref(c), C.byref(per)), "adk_program_graph_stats")
+        return int(r.value), int(c.value), int(per.value)
 
     def set_workgroups(self, workgroups):
         """Persistent workgroups per stream-K launch (0 = whole chip); see adk_program_set_workgroups."""

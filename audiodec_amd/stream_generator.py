@@ -55,6 +55,7 @@ class _StreamBase:
         self.offline = False
         self.workgroups = 0
         self.split16 = os.environ.get("ADK_SPLIT16", "0") == "1"
+        self.graph = os.environ.get("ADK_GRAPH", "0") == "1"
         self._warm = {}
 
     # ---- torch.nn.Module surface the reference's loader touches (bin/stream.py:59-61) ----
@@ -87,6 +88,16 @@ class _StreamBase:
             self._drop_programs()
         return self
 
+    def set_graph(self, on=True):
+        """Replay the steady state of every program of this model as HIP graphs (adk_program_set_graph): one hipGraphLaunch per
+        program and step instead of ~30 kernel launches, for steps of exactly max_frames hops.  The rings are sized so that
+        their cursors cycle with a short period (more history rows than the layers need; state memory grows ~1.5x).  Results are
+        bit-identical to the eager path.  Default off (env ADK_GRAPH=1 flips it)."""
+        if bool(on) != self.graph:
+            self.graph = bool(on)
+            self._drop_programs()
+        return self
+
     def set_workgroups(self, workgroups):
         """Share of the chip the stream-K conv launches of this model assume (persistent workgroups, 0 = all):
         for callers that step several models concurrently on different HIP streams."""
@@ -100,7 +111,7 @@ class _StreamBase:
         return list(self._programs().values())
 
     def _new_program(self, builder):
-        pr = program.HipProgram(builder, self.num_streams, self.max_frames, self._dev())
+        pr = program.HipProgram(builder, self.num_streams, self.max_frames, self._dev(), graph=self.graph and not self.offline)
         if self.workgroups:
             pr.set_workgroups(self.workgroups)
         return pr

@@ -448,6 +448,8 @@ def main():
     ap.add_argument("--stages", type=str, default="2",
                     help="vocoder lowering: 1 = one program; 2 = two programs cut in front of upsample stage 2, the second on a "
                          "third HIP stream (default); or explicit cut points, e.g. 1,2 = three programs on three streams")
+    ap.add_argument("--graph", choices=("0", "1"), default=os.environ.get("ADK_BENCH_GRAPH", "0"),
+                    help="1: replay each program's steady state as HIP graphs (adk_program_set_graph); results are bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-cfg1", action="store_true", help="skip BASELINE config 1 (file round trip) on the host CPU")
     ap.add_argument("--no-self-check", action="store_true", help="skip the parity check of the timed configuration against the CPU oracle")
@@ -460,6 +462,7 @@ def main():
     __graft_entry__.build()
     os.environ["ADK_SPLIT16"] = "1" if args.precision == "split16" else "0"    # read by the generators at construction
     os.environ["ADK_VOCODER_STAGES"] = str(args.stages)
+    os.environ["ADK_GRAPH"] = args.graph
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -568,6 +571,8 @@ def main():
                               "|err|/sum|a b| vs fp64 8e-8 (f32 MFMA chain: 2e-7), profiles/r1_f16_split_probe.txt; both modes pass "
                               "the same parity tests (waveform <= 1e-4 vs the reference, RVQ indices bit-exact)"
                               if args.precision == "split16" else "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"},
+        "executor": ("HIP graphs: one captured launch sequence per program and cursor phase, replayed by hipGraphLaunch (ops on caller buffers stay "
+                     "ordinary launches)") if args.graph == "1" else "ordinary launches from the C++ program runner (one C call per program and step)",
         "frames_per_s_per_gpu": round(frames / elapsed / world, 1),
         "latency_ms": {},
         "realtime_streams_supported_per_gpu": int(frames / elapsed / world / 160.0),

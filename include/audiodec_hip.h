@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 6
+#define ADK_ABI_VERSION 7
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -232,6 +232,17 @@ int adk_program_reset(adk_program* p, void* stream);
  * chip, 2 per CU).  A caller that runs several programs CONCURRENTLY on different HIP streams (software pipeline over
  * batches, bench.py) gives each a share: at 3 concurrent programs 256 measured best (210 k vs 189 k frames/s). */
 int adk_program_set_workgroups(adk_program* p, int32_t workgroups);
+/* Replay the steady state as HIP graphs (hipStreamBeginCapture / hipGraphLaunch): the ops between the first and the last
+ * one that touch caller buffers are captured once per cursor PHASE and replayed by one hipGraphLaunch per step; the ops on
+ * caller buffers (audio / codes in, waveform out) stay ordinary launches because their pointers change from call to call.
+ * Ring cursors are kernel arguments, so a captured launch sequence is only valid for the cursor state it was captured in:
+ * that state repeats with a short period when every ring length is a small multiple of its per-step advance
+ * (max_frames * rate) -- the caller sizes the rings so by rounding `hist` up (audiodec_amd/program.py does); otherwise this
+ * call fails and the program stays eager.  Only steps of exactly max_frames frames in a recognised phase replay; any other
+ * step (short chunk, first step after reset, profiling) runs eagerly, results are identical either way.  The stream-K publish
+ * flags are zeroed by a memset node at the head of each graph (their per-launch epochs are frozen by the capture). */
+int adk_program_set_graph(adk_program* p, int32_t enabled);
+int adk_program_graph_stats(const adk_program* p, int64_t* replays, int64_t* captures, int32_t* period);
 /* ring cursors (n_rings int32), for snapshot / restore of a warmed-up state together with the arena */
 int adk_program_get_cursors(const adk_program* p, int32_t* cursors, int32_t n);
 int adk_program_set_cursors(adk_program* p, const int32_t* cursors, int32_t n);

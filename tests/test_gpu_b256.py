@@ -235,3 +235,55 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
     assert out["n_gpus"] == 2 and out["config"]["streams_total"] == 512 and out["config"]["streams_per_gpu"] == 256
     assert out["scaling"] == "weak" and out["steps"] == 6 and out["device_error_flags"] == 0
     assert out["value"] > 0 and abs(out["value"] - 512 * 6 / (out["ms_per_step"] * 6e-3)) < 0.01 * out["value"]
+
+
+@pytest.mark.parametrize("split16", [True, False], ids=["split16", "f32"])
+def test_graph_replay_is_bit_identical_to_eager(gpu, ckpt_root, split16):
+    """adk_program_set_graph: the captured launch sequences (one per cursor phase, period 12 at one frame per step) replay the
+    same kernels with the same arguments, so every output bit equals the eager path -- across more than two periods, a
+    reset_buffer + re-warm, a per-stream reset, and short steps in between (which run eagerly and leave the phase)."""
+    hop, B, steps = HOP, 6, 40
+    audio = np.stack([synth.synth_audio(321, s, (steps + 8) * hop) for s in range(B)])
+    old = os.environ.get("ADK_GRAPH")
+    try:
+        os.environ["ADK_GRAPH"] = "0"
+        ad_e = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 2, split16)
+        os.environ["ADK_GRAPH"] = "1"
+        ad_g = load_audiodec(ckpt_root, "vctk_v1", 1337, B, 2, split16)
+    finally:
+        if old is None:
+            os.environ.pop("ADK_GRAPH", None)
+        else:
+            os.environ["ADK_GRAPH"] = old
+    assert ad_g.tx_encoder.graph and ad_g.decoder.graph and not ad_e.decoder.graph
+    assert ad_g.decoder._decoder().graph and ad_g.tx_encoder._encoder().graph          # the C++ side accepted the ring sizes
+
+    def run(ad, x):
+        idx = ad.tx_encoder.quantize(ad.tx_encoder.encode(x))
+        return idx, ad.decoder.decode(ad.rx_encoder.lookup(idx))
+
+    pos = 0
+    with torch.no_grad():
+        for i in range(steps):
+            frames = 1 if i in (17, 18, 19) else 2                 # three short steps: eager, and the phase is left for a while
+            x = torch.from_numpy(audio[:, pos:pos + frames * hop])[:, None, :].to(DEV)
+            pos += frames * hop
+            if pos + 2 * hop > audio.shape[1]:
+                pos = 0
+            (ie, ye), (ig, yg) = run(ad_e, x), run(ad_g, x)
+            assert torch.equal(ie, ig) and torch.equal(ye, yg), i
+            if i == 25:                                            # whole-model reset + warm-up, then a per-stream reset
+                for ad in (ad_e, ad_g):
+                    ad.tx_encoder.reset_buffer(); ad.rx_encoder.reset_buffer(); ad.decoder.reset_buffer()
+                    ad.tx_encoder.initial_encoder(8192, DEV)
+                    ad.decoder.initial_decoder(ad.rx_encoder.initial_encoder(8192, DEV))
+            if i == 30:
+                for ad in (ad_e, ad_g):
+                    ad.tx_encoder.reset_stream(2); ad.decoder.reset_stream(2)
+    rep, cap, per = ad_g.decoder._decoder().graph_stats()
+    assert per >= 1 and rep > 0 and 0 < cap <= per, (rep, cap, per)
+    rep_e, cap_e, per_e = ad_g.tx_encoder._encoder().graph_stats()
+    assert rep_e > 0 and cap_e <= per_e
+    assert ad_e.decoder._decoder().graph_stats() == (0, 0, 0)
+    from audiodec_amd import native
+    assert native.device_flags() == 0
