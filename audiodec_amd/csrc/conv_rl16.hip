@@ -33,6 +33,12 @@ struct Rl16Args {
     int ksteps;           // 16-k chunks per m-tile in the packed weights (K padded to a multiple of 64)
     unsigned w_bytes;
     int* err;             // sticky device flags
+    // FUSE: the 1x1 conv of a residual unit that consumes this conv's output (residual_unit.py:78-81: x + conv2(act(conv1(act(x)))))
+    const float* w2;      // its split16 fragments ([1 group][C/32 m-tiles][C/16 chunks][hi|lo][64][8 halfs])
+    const float* bias2;   // or nullptr
+    float* out2; int out2_rows, out2_ch, out2_cursor, out2_choff;
+    const float* res2; int res2_rows, res2_ch, res2_cursor, res2_choff;
+    int act_out2;
 };
 
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
@@ -60,7 +66,13 @@ __device__ __forceinline__ f16x8 as_f16x8(const u32x4s& v) {
 
 // NW waves per workgroup; each wave owns work items (m-tile, pair of consecutive n-tiles) and keeps each
 // weight fragment in registers for both n-tiles.  PF = weight prefetch distance in 16-k chunks.
-template <int C, int ACT, int TAPS, int NW, int PF>
+// FUSE = true: residual unit in one launch.  Phase 1 is the K-tap conv exactly as below, but its result (h) stays in registers;
+// after a barrier (every wave is done reading the staged rows) each lane writes act(h), split into f16 hi / lo, over the staged
+// rows -- the layout the 1x1 conv's B fragments are read from -- and after a second barrier the same wave runs the 1x1 conv for
+// the same (m-tile, n-tile pair), adds bias / residual x and stores.  h never goes to memory (the unfused path writes and
+// re-reads 4 bytes per element per stream) and one launch disappears.  Needs at most one work item per wave (the launch
+// checks); operations and their order per output element are those of the two separate kernels, so the result is bit-identical.
+template <int C, int ACT, int TAPS, int NW, int PF, bool FUSE = false>
 __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3)) void conv_rl16_kernel(ConvArgs a, Rl16Args rl) {   // all-weights-up-front variants: 256 VGPRs
     constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
     constexpr int CH = C / 16;                         // 16-k chunks per tap
@@ -111,6 +123,20 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
         }
     }
 
+    // FUSE: all fragments of the 1x1 conv for this wave's m-tile (C/16 chunks), fetched in the same round trip
+    constexpr int ST2 = FUSE ? C / 16 : 1;
+    u32x4s a2h[ST2], a2l[ST2];
+    if constexpr (FUSE) {
+        constexpr int KS2 = (C + 63) / 64 * 4;         // chunks per m-tile in the packed layout (K padded to a multiple of 64)
+        const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rl.w2), 0, (unsigned)((C / 32) * KS2 * 2048), 0x00020000);
+        const unsigned wb2 = (unsigned)(first_mt * KS2) * 2048u;   // a wave without an item reads past the end: zeros
+#pragma unroll
+        for (int s2 = 0; s2 < ST2; ++s2) {
+            a2h[s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w2, lane16, wb2 + (unsigned)s2 * 2048u, 0);
+            a2l[s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w2, lane16 + 1024u, wb2 + (unsigned)s2 * 2048u, 0);
+        }
+    }
+
     // ---- stage rows [t0 - span, t0 + 32*n_tiles): activation, split into hi / lo halves ----
     {
         const float* xin = a.in + (size_t)b * a.in_rows * a.in_ch + a.in_choff + g * a.in_gstride;
@@ -153,11 +179,13 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
     }
     __syncthreads();
 
+    f32x16 m0, m1, c0, c1;                              // main / cross-term accumulators of the two n-tiles
+    int mt = 0, nt0 = 0;
+    bool two = false;
     for (int item = rot; item < items; item += NW) {
-        const int mt = item / n_pairs, nt0 = 2 * (item - mt * n_pairs);
-        const bool two = nt0 + 1 < n_tiles;
+        mt = item / n_pairs; nt0 = 2 * (item - mt * n_pairs);
+        two = nt0 + 1 < n_tiles;
         const unsigned wbase = (unsigned)((g * m_tiles + mt) * rl.ksteps) * 2048u;
-        f32x16 m0, m1, c0, c1;                          // main / cross-term accumulators of the two n-tiles
 #pragma unroll
         for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
         const unsigned char* x0 = xs + (nt0 * 32 + l31) * RS + 16 * lh;
@@ -192,6 +220,7 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
             }
         }
+        if constexpr (FUSE) break;                      // at most one item per wave; phase 2 below consumes the accumulators
         // ---- epilogue: acc0 + acc1/2048, bias, residual, output activation, store.  An operand beyond the f16 range was
         // split into inf parts, so every output it feeds is non-finite: checked here, once per output ----
         bool bad = false;
@@ -239,6 +268,109 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
                     dst = outb + (size_t)r2 * a.out_ch + (ml - ph * a.cout_real);
                 }
                 if (!(ADK_RL16_DBG & 2) || v.x == 1.2345e-30f) *reinterpret_cast<float4*>(dst) = v;
+            }
+        }
+        if (bad) atomicOr(rl.err, 8);
+    }
+    if constexpr (FUSE) {
+        const bool has_item = rot < items;
+        bool bad = false;
+        __syncthreads();                                // every wave is done reading the staged rows of phase 1
+        if (has_item) {
+            // h = acc0 + acc1/2048 (+ bias): what the unfused kernel stores; act(h), split, goes over the staged rows [0, 32*n_tiles)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1 && !two) break;
+                const f32x16& am = j ? m1 : m0;
+                const f32x16& ac = j ? c1 : c0;
+                unsigned char* row = xs + ((nt0 + j) * 32 + l31) * RS;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int ml = mt * 32 + 8 * qd + 4 * lh;
+                    float h[4] = {fmaf(ac[4 * qd], kLoInv, am[4 * qd]), fmaf(ac[4 * qd + 1], kLoInv, am[4 * qd + 1]),
+                                  fmaf(ac[4 * qd + 2], kLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kLoInv, am[4 * qd + 3])};
+                    bad |= !(fabsf(h[0]) <= 3.0e38f) | !(fabsf(h[1]) <= 3.0e38f) | !(fabsf(h[2]) <= 3.0e38f) | !(fabsf(h[3]) <= 3.0e38f);
+                    if (a.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + g * a.cout_g + ml);
+                        h[0] += bb.x; h[1] += bb.y; h[2] += bb.z; h[3] += bb.w;
+                    }
+                    typedef _Float16 f16x4r __attribute__((ext_vector_type(4)));
+                    f16x4r hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = rl16_act<ACT>(h[e], a.slope);
+                        const _Float16 hh = (_Float16)y;
+                        hi[e] = hh;
+                        lo[e] = (_Float16)((y - (float)hh) * kLoScale);
+                    }
+                    *reinterpret_cast<f16x4r*>(row + 2 * ml) = hi;
+                    *reinterpret_cast<f16x4r*>(row + 2 * C + 2 * ml) = lo;
+                }
+            }
+        }
+        __syncthreads();                                // act(h) of all channels of this wave's time steps is in LDS
+        if (has_item) {
+            f32x16 q0, q1, r0, r1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { q0[e] = 0.f; q1[e] = 0.f; r0[e] = 0.f; r1[e] = 0.f; }
+            const unsigned char* x0 = xs + (nt0 * 32 + l31) * RS + 16 * lh;
+            const unsigned char* x1 = x0 + 32 * RS;
+#pragma unroll
+            for (int s2 = 0; s2 < ST2; ++s2) {          // the 1x1 conv: same MFMA sequence as conv_rl16_kernel<C, ACT, 1, ...>
+                const f16x8 Ah = as_f16x8(a2h[s2]), Al = as_f16x8(a2l[s2]);
+                const f16x8 b0h = *reinterpret_cast<const f16x8*>(x0 + 32 * s2);
+                const f16x8 b0l = *reinterpret_cast<const f16x8*>(x0 + 32 * s2 + 2 * C);
+                if (two) {
+                    const f16x8 b1h = *reinterpret_cast<const f16x8*>(x1 + 32 * s2);
+                    const f16x8 b1l = *reinterpret_cast<const f16x8*>(x1 + 32 * s2 + 2 * C);
+                    q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, q0, 0, 0, 0);
+                    q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1h, q1, 0, 0, 0);
+                    r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, r0, 0, 0, 0);
+                    r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1l, r1, 0, 0, 0);
+                    r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, r0, 0, 0, 0);
+                    r1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b1h, r1, 0, 0, 0);
+                } else {
+                    q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, q0, 0, 0, 0);
+                    r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, r0, 0, 0, 0);
+                    r0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, r0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1 && !two) break;
+                const f32x16& am = j ? q1 : q0;
+                const f32x16& ac = j ? r1 : r0;
+                const int t = t0 + (nt0 + j) * 32 + l31;
+                if (t >= t0 + tcur) continue;
+                const float* resp = nullptr;
+                if (rl.res2) {
+                    int rrow = rl.res2_cursor + t;
+                    if (rrow >= rl.res2_rows) rrow -= rl.res2_rows;
+                    resp = rl.res2 + ((size_t)b * rl.res2_rows + rrow) * rl.res2_ch + rl.res2_choff;
+                }
+                int orow = rl.out2_cursor + t;
+                if (orow >= rl.out2_rows) orow -= rl.out2_rows;
+                float* outp = rl.out2 + ((size_t)b * rl.out2_rows + orow) * rl.out2_ch + rl.out2_choff;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int ml = mt * 32 + 8 * qd + 4 * lh;
+                    float4 v = make_float4(fmaf(ac[4 * qd], kLoInv, am[4 * qd]), fmaf(ac[4 * qd + 1], kLoInv, am[4 * qd + 1]),
+                                           fmaf(ac[4 * qd + 2], kLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kLoInv, am[4 * qd + 3]));
+                    bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
+                    if (rl.bias2) {
+                        const float4 bb = *reinterpret_cast<const float4*>(rl.bias2 + ml);
+                        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                    }
+                    if (resp) {
+                        const float4 rr = *reinterpret_cast<const float4*>(resp + ml);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
+                    if (rl.act_out2 != ADK_ACT_NONE) {
+                        v.x = act_apply(v.x, rl.act_out2, 0.f); v.y = act_apply(v.y, rl.act_out2, 0.f);
+                        v.z = act_apply(v.z, rl.act_out2, 0.f); v.w = act_apply(v.w, rl.act_out2, 0.f);
+                    }
+                    *reinterpret_cast<float4*>(outp + ml) = v;
+                }
             }
         }
         if (bad) atomicOr(rl.err, 8);
@@ -373,6 +505,74 @@ int launch_conv_rl16(const ConvArgs& a, hipStream_t s) {
     const bool five = items % 5 == 0;
     if (a.cin_g == 32) return five ? launch_rl16<32, 5>(a, s, tt) : launch_rl16<32, 4>(a, s, tt);
     return five ? launch_rl16<64, 5>(a, s, tt) : launch_rl16<64, 4>(a, s, tt);
+}
+
+
+// ---- residual unit in one launch: K-tap conv (a1) -> 1x1 conv with residual (a2), see conv_rl16_kernel<..., FUSE> ----
+bool conv_rl16_fusable(const ConvArgs& a1, const ConvArgs& a2) {
+    if (!conv_rl16_preferred(a1) || !a2.wfrag) return false;
+    if (a1.taps != 7 || a1.up != 1 || a1.groups != 1 || a1.res || a1.act_out != ADK_ACT_NONE) return false;
+    if (a2.taps != 1 || a2.up != 1 || a2.groups != 1 || a2.stride != 1) return false;
+    if (a2.cin_g != a1.cout_g || a2.cout_g != a1.cout_g || a1.cin_g != a1.cout_g) return false;          // C -> C -> C
+    if (a2.act_in != a1.act_in || a2.slope != a1.slope || a2.batch != a1.batch || a2.t_out != a1.t_out) return false;
+    if (a2.in != a1.out || a2.in_rows != a1.out_rows || a2.in_ch != a1.out_ch || a2.in_choff != a1.out_choff) return false;   // h feeds only the 1x1
+    if ((a2.out_ch % 4) || (a2.out_choff % 4) || (reinterpret_cast<uintptr_t>(a2.out) & 15) || (reinterpret_cast<uintptr_t>(a2.wfrag) & 15)) return false;
+    if (a2.res && ((a2.res_ch % 4) || (a2.res_choff % 4) || (reinterpret_cast<uintptr_t>(a2.res) & 15))) return false;
+    if (a2.bias && (reinterpret_cast<uintptr_t>(a2.bias) & 15)) return false;
+    return true;
+}
+
+namespace {
+template <int C, int NW>
+int launch_rl16_fused(const ConvArgs& a, const ConvArgs& a2, hipStream_t s, int tt) {
+    Rl16Args rl;
+    rl.span = (a.taps - 1) * a.dilation;
+    rl.mt32_per_g = a.cout_g / 32;
+    rl.ksteps = (a.ktot + 63) / 64 * 4;
+    rl.w_bytes = (unsigned)((unsigned long long)a.groups * rl.mt32_per_g * rl.ksteps * 2048ull);
+    rl.err = flags_word();
+    rl.tt = tt;
+    rl.tiles_per_stream = (a.t_out + tt - 1) / tt;
+    rl.w2 = a2.wfrag; rl.bias2 = a2.bias;
+    rl.out2 = a2.out; rl.out2_rows = a2.out_rows; rl.out2_ch = a2.out_ch; rl.out2_cursor = a2.out_cursor; rl.out2_choff = a2.out_choff;
+    rl.res2 = a2.res; rl.res2_rows = a2.res_rows; rl.res2_ch = a2.res_ch; rl.res2_cursor = a2.res_cursor; rl.res2_choff = a2.res_choff;
+    rl.act_out2 = a2.act_out;
+    constexpr int RS = 4 * C + 16;
+    const int tt_pad = (std::min(tt, a.t_out) + 31) / 32 * 32;
+    const size_t lds = (size_t)(rl.span + tt_pad) * RS;
+    const long long blocks = (long long)a.batch * rl.tiles_per_stream;
+    if (blocks > 0x7fffffffLL || lds > 64 * 1024) return fail(ADK_ERR_SHAPE, "conv: fused residual unit does not fit");
+    auto go = [&](auto kern) -> int {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * NW), lds, s, a, rl);
+        ADK_HIP_CHECK(hipGetLastError());
+        return ADK_OK;
+    };
+    if (a.act_in == ADK_ACT_ELU) return go(conv_rl16_kernel<C, ADK_ACT_ELU, 7, NW, 2, true>);
+    if (a.act_in == ADK_ACT_LEAKY) return go(conv_rl16_kernel<C, ADK_ACT_LEAKY, 7, NW, 2, true>);
+    return go(conv_rl16_kernel<C, ADK_ACT_NONE, 7, NW, 2, true>);
+}
+}  // namespace
+
+// 0 = launched; ADK_ERR_STATE = the pair cannot be fused for this call (the caller launches the two ops separately)
+int launch_conv_rl16_fused(const ConvArgs& a, const ConvArgs& a2, hipStream_t s) {
+    if (a.n_total == 0) return ADK_OK;
+    if (!conv_rl16_fusable(a, a2)) return ADK_ERR_STATE;
+    // the same time tiling as launch_conv_rl16 (so that phase 1 is the same launch), then: at most one item per wave
+    const int rs = 4 * a.cin_g + 16;
+    const int span = (a.taps - 1) * a.dilation;
+    int tt = ((54000 / rs - span) / 32) * 32;
+    if (tt < 32) return ADK_ERR_STATE;
+    if (tt >= a.t_out) tt = a.t_out;
+    if (tt >= a.t_out && (a.t_out + 31) / 32 >= 8) tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
+    else if (tt >= a.t_out && (a.t_out + 31) / 32 >= 4 && (a.cout_g / 32) * (((a.t_out + 31) / 32 + 1) / 2) > 4 &&
+             (a.cout_g / 32) * ((((a.t_out + 31) / 32 + 1) / 2 + 1) / 2) <= 4)
+        tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
+    const int n_tiles = (std::min(tt, a.t_out) + 31) / 32;
+    const int items = (a.cout_g / 32) * ((n_tiles + 1) / 2);
+    if (items > 5) return ADK_ERR_STATE;
+    const bool five = items == 5;
+    if (a.cin_g == 32) return five ? launch_rl16_fused<32, 5>(a, a2, s, tt) : launch_rl16_fused<32, 4>(a, a2, s, tt);
+    return five ? launch_rl16_fused<64, 5>(a, a2, s, tt) : launch_rl16_fused<64, 4>(a, a2, s, tt);
 }
 
 }  // namespace adk

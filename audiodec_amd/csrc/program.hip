@@ -170,6 +170,31 @@ extern "C" int adk_causal_conv_describe(const adk_conv_desc* d, adk_ring_view in
     return ADK_OK;
 }
 
+extern "C" int adk_causal_conv_time(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
+                                    int32_t batch, int32_t t_out, int32_t impl, int32_t iters, void* stream, float* avg_us) {
+    if (!d || !avg_us || iters <= 0) return fail(ADK_ERR_ARG, "adk_causal_conv_time: bad arguments");
+    ConvArgs a;
+    int rc = build_args(*d, in, out, res, batch, t_out, a);
+    if (rc != ADK_OK) return rc;
+    DeviceGuard guard(device_of(out.base));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static thread_local Workspace tls_ws[kMaxDevices];
+    Workspace& ws = tls_ws[current_device()];
+    for (int i = 0; i < 5 && rc == ADK_OK; ++i) rc = run_conv(a, impl, s, ws);       // warm-up (first-use attributes, caches)
+    if (rc != ADK_OK) return rc;
+    hipEvent_t e0, e1;
+    ADK_HIP_CHECK(hipEventCreate(&e0)); ADK_HIP_CHECK(hipEventCreate(&e1));
+    ADK_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters && rc == ADK_OK; ++i) rc = run_conv(a, impl, s, ws);
+    ADK_HIP_CHECK(hipEventRecord(e1, s));
+    ADK_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    ADK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = 1e3f * ms / (float)iters;
+    return rc;
+}
+
 extern "C" int64_t adk_packed_weight_floats(int32_t groups, int32_t cout_g, int32_t ktot) {
     if (groups <= 0 || cout_g <= 0 || ktot <= 0 || ktot % 8) return -1;
     return (int64_t)groups * ((cout_g + 31) / 32) * ((ktot + 63) / 64 * 8) * 256;
@@ -323,21 +348,43 @@ static adk_ring_view view_of(const adk_program* p, int id, int frames, void* con
     return v;
 }
 
-// one op of the launch sequence on stream s
-static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream_t s) {
+static int op_conv_args(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a) {
+    const adk_op_desc& o = p->ops[i];
+    adk_conv_desc d = o.conv;
+    d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
+    d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;
+    d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
+    adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
+    adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
+    adk_ring_view res; memset(&res, 0, sizeof(res));
+    if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
+    return build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+}
+
+// Can ops i, i+1 (a residual unit: conv -> 1x1 + residual) run as one launch for a `frames`-hop step?
+static bool op_pair_fusable(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a1, ConvArgs& a2) {
+    read_env();
+    if (i + 1 >= (int)p->ops.size()) return false;
+    const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
+    if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16 || o2.impl != ADK_IMPL_SPLIT16) return false;
+    if (o2.in_ring != o1.out_ring || p->rings[o1.out_ring].external >= 0 || !g_use_rl) return false;
+    if (op_conv_args(p, i, frames, ext, a1) != ADK_OK || op_conv_args(p, i + 1, frames, ext, a2) != ADK_OK) return false;
+    return conv_rl16_fusable(a1, a2);
+}
+
+// one op of the launch sequence on stream s; *consumed = 2 when the op was launched together with its successor
+static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream_t s, int* consumed = nullptr) {
     const adk_op_desc& o = p->ops[i];
     int rc = ADK_OK;
+    if (consumed) *consumed = 1;
     if (o.kind == ADK_OP_CONV) {
-        adk_conv_desc d = o.conv;
-        d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
-        d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;
-        d.bias = o.b_off >= 0 ? p->weights + o.b_off : nullptr;
-        adk_ring_view in = view_of(p, o.in_ring, frames, ext, o.in_ch_off);
-        adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
-        adk_ring_view res; memset(&res, 0, sizeof(res));
-        if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
-        ConvArgs a;
-        rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+        ConvArgs a, a2;
+        if (consumed && o.fuse_next && op_pair_fusable(p, i, frames, ext, a, a2)) {
+            rc = launch_conv_rl16_fused(a, a2, s);
+            if (rc == ADK_OK) { *consumed = 2; return ADK_OK; }
+            if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (fused): " + g_err; return rc; }
+        }
+        rc = op_conv_args(p, i, frames, ext, a);
         if (rc == ADK_OK) rc = run_conv(a, o.impl, s, p->ws);
     } else if (o.kind == ADK_OP_MEAN) {
         RingMeanArgs m;
@@ -450,7 +497,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
     }
     // HIP-graph replay: full-size steps of a warmed-up program in a known cursor phase (see adk_program_set_graph)
     const int phase = (p->graph && !p->profiling && !p->fresh && frames == p->max_frames) ? graph_phase(p) : -1;
-    const bool replay = phase >= 0 && p->seen[phase];
+    const bool replay = phase >= 0 && p->seen[phase] && s != nullptr;      // the legacy default stream cannot be captured: eager there
     if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[0], s));
     for (int i = 0; i < n_ops; ++i) {
         if (replay && i == p->g_lo) {
@@ -463,7 +510,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
                 int rc = ADK_OK;
                 hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(p->ws.ptr) + p->ws.flags_offset, 0, p->ws.bytes - p->ws.flags_offset, s);
                 if (e != hipSuccess) rc = fail(ADK_ERR_HIP, std::string("graph capture: memset: ") + hipGetErrorString(e));
-                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK; ++k) rc = run_op(p, k, frames, ext, s);
+                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK;) { int used = 1; rc = run_op(p, k, frames, ext, s, &used); k += used; }
                 e = hipStreamEndCapture(s, &g);
                 if (rc != ADK_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
                 if (e != hipSuccess || !g) return fail(ADK_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -479,9 +526,14 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
             i = p->g_hi - 1;
             continue;
         }
-        int rc = run_op(p, i, frames, ext, s);
+        int used = 1;
+        int rc = run_op(p, i, frames, ext, s, (i + 1 < n_ops && !(replay && i + 1 == p->g_lo)) ? &used : nullptr);
         if (rc != ADK_OK) return rc;
         if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[i + 1], s));
+        if (used == 2) {                      // the successor ran inside the same launch
+            ++i;
+            if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[i + 1], s));
+        }
     }
     if (phase >= 0) p->seen[phase] = 1;
     for (size_t i = 0; i < p->rings.size(); ++i)
@@ -511,6 +563,9 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
         name = conv_kernel_name(a, o.impl);
+        ConvArgs f1, f2;
+        if (o.fuse_next && op_pair_fusable(p, op, frames, ext, f1, f2)) name = f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>";
+        else if (op > 0 && p->ops[op - 1].fuse_next && op_pair_fusable(p, op - 1, frames, ext, f1, f2)) name = "(fused into the previous op)";
     }
     snprintf(buf, n, "%s", name.c_str());
     return ADK_OK;

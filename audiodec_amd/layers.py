@@ -66,7 +66,7 @@ class _CausalBase:
                                                  None, None, B, L, native.current_stream(self.dev)), "adk_ring_write")
         return L
 
-    def _run(self, d, t_out, out_rows, out_ch, residual=None):
+    def _run(self, d, t_out, out_rows, out_ch, residual=None, time_iters=0):
         out = torch.empty(self.batch, out_rows, out_ch, device=self.dev)
         res_view = _view(None, 0, 0, 0)
         if residual is not None:
@@ -88,6 +88,11 @@ class _CausalBase:
         native.check(native.lib().adk_causal_conv_describe(C.byref(d), in_view, out_view, res_view, self.batch, t_out, self.impl, buf, 64),
                      "adk_causal_conv_describe")
         self.last_kernel = buf.value.decode()          # which kernel this call runs (tests, profiles)
+        if time_iters:
+            us = C.c_float(0.0)
+            native.check(native.lib().adk_causal_conv_time(C.byref(d), in_view, out_view, res_view, self.batch, t_out, self.impl, int(time_iters),
+                                                           native.current_stream(self.dev), C.byref(us)), "adk_causal_conv_time")
+            return float(us.value)
         native.check(native.lib().adk_causal_conv(
             C.byref(d), in_view, out_view, res_view, self.batch, t_out, self.impl, native.current_stream(self.dev)), "adk_causal_conv")
         return out
@@ -156,16 +161,25 @@ class CausalConvTranspose1d(_CausalBase):
         self.b_packed = self.bias.repeat(self.stride).to(self.dev) if self.bias is not None else None
         return self
 
-    def inference(self, x):
-        L = self._push(x)
+    def _desc(self):
         d = ConvDesc()
         d.cin_g, d.cout_g, d.groups = self.in_channels, self.stride * self.out_channels, 1
         d.taps, d.stride, d.dilation, d.hist = 2, 1, 1, 1
         d.up, d.cout_real = self.stride, self.out_channels
         d.in_group_stride, d.res_group_stride = d.cin_g, d.cout_g
-        out = self._run(d, L, L * self.stride, self.out_channels)
+        return d
+
+    def inference(self, x):
+        L = self._push(x)
+        out = self._run(self._desc(), L, L * self.stride, self.out_channels)
         self.cursor = (self.cursor + L) % self.rows
         return out.transpose(1, 2)
+
+    def time_kernel(self, L, iters=300):
+        """Average microseconds of the conv launch of inference() alone, on the rows already in the ring (no new input, no state
+        change): `iters` back-to-back launches timed by HIP events inside the library (adk_causal_conv_time) -- bench.py's
+        roofline of the last up-sampling stage."""
+        return self._run(self._desc(), L, L * self.stride, self.out_channels, time_iters=iters)
 
 
 class ResidualVQ:

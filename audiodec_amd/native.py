@@ -41,7 +41,7 @@ class OpDesc(C.Structure):
                 ("in_ch_off", C.c_int32), ("out_ch_off", C.c_int32), ("res_ch_off", C.c_int32),
                 ("rate_out", C.c_int32), ("conv", ConvDesc), ("w_off", C.c_int64), ("wf_off", C.c_int64), ("b_off", C.c_int64),
                 ("mean_off", C.c_int64), ("scale_off", C.c_int64), ("ext_src", C.c_int32),
-                ("mean_rings", C.c_int32 * 4), ("n_mean", C.c_int32), ("impl", C.c_int32)]
+                ("mean_rings", C.c_int32 * 4), ("n_mean", C.c_int32), ("impl", C.c_int32), ("fuse_next", C.c_int32)]
 
 
 # every symbol include/audiodec_hip.h declares: (restype, argtypes)
@@ -53,6 +53,7 @@ SYMBOLS = {
     "adk_set_conv_cfg": (C.c_int, [_i32]),
     "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
     "adk_causal_conv_describe": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, C.c_char_p, _i32]),
+    "adk_causal_conv_time": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _i32, _vp, C.POINTER(C.c_float)]),
     "adk_packed_weight_floats": (C.c_int64, [_i32, _i32, _i32]),
     "adk_pack_weights_mfma": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "adk_ring_write": (C.c_int, [_vp, RingView, _vp, _vp, _i32, _i32, _vp]),

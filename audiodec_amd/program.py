@@ -16,6 +16,7 @@ Lowering rules (reference semantics preserved op for op):
     input and on the first residual (models/vocoder/modules/multi_fusion.py:133-141)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -108,6 +109,9 @@ def mfma_eligible(cin_g, cout_g, groups):
     return cin_g % 32 == 0 and cout_g % 4 == 0 and groups * cout_g >= 32
 
 
+FUSE_RES_UNITS = os.environ.get("ADK_FUSE", "1") != "0"      # ADK_FUSE=0: every residual unit as two launches (A/B, cross-checks)
+
+
 class Blob:
     """Packed fp32 weights; every tensor starts on a 16-byte boundary."""
 
@@ -196,7 +200,7 @@ class Builder:
         self.op_names.append("hist_replicate")
 
     def conv(self, name, in_ring, out_ring, act_in=ACT_NONE, slope=0.0, act_out=ACT_NONE, res_ring=-1,
-             in_group_stride=None, res_group_stride=None, impl=IMPL_AUTO):
+             in_group_stride=None, res_group_stride=None, impl=IMPL_AUTO, fuse_next=False):
         s = self.specs[name]
         w = effective_weight(self.sd, s)
         bias = self.sd[s.wkey("bias")].float() if s.bias else None
@@ -241,6 +245,7 @@ class Builder:
         op.mean_off = op.scale_off = -1
         op.ext_src = -1
         op.impl = impl
+        op.fuse_next = 1 if fuse_next else 0
         self.ops.append(op)
         self.op_names.append(name)
         self.flops_per_frame += 2 * packed.numel() * rate_out
@@ -263,7 +268,8 @@ def _res_units(b, pre, x_ring, c, rate, act, slope, out_ring_of_last):
     """3x CausalResidualUnit.inference; returns the ring holding the block output."""
     for j in range(3):
         h = b.scratch_ring(c, rate, "h")
-        b.conv(f"{pre}.res_units.{j}.conv1", x_ring, h, act, slope)
+        # h is read by conv2 only: the runner may run the unit as one kernel (adk_op_desc.fuse_next)
+        b.conv(f"{pre}.res_units.{j}.conv1", x_ring, h, act, slope, fuse_next=FUSE_RES_UNITS)
         nxt = out_ring_of_last if j == 2 else b.ring(c, 0, rate)
         b.conv(f"{pre}.res_units.{j}.conv2", h, nxt, act, slope, res_ring=x_ring)
         x_ring = nxt

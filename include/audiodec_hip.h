@@ -130,6 +130,10 @@ int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out,
  * for tests that must know which kernel they exercised */
 int adk_causal_conv_describe(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
                              int32_t batch, int32_t t_out, int32_t impl, char* buf, int32_t n);
+/* timing aid (bench.py, tools): `iters` back-to-back launches of the call above on `stream`, bracketed by HIP events recorded
+ * on that stream; synchronises; *avg_us = average microseconds per launch (no host language in the loop) */
+int adk_causal_conv_time(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
+                         int32_t batch, int32_t t_out, int32_t impl, int32_t iters, void* stream, float* avg_us);
 
 /*
  * Copy caller rows into a ring, optionally normalising: ring row = (src - mean) / scale.
@@ -217,6 +221,9 @@ typedef struct {
                                             models/vocoder/modules/multi_fusion.py:73-79)              */
     int32_t n_mean;
     int32_t impl;                        /* ADK_IMPL_*                                                */
+    int32_t fuse_next;                   /* 1: this conv's output ring is read only by the NEXT op, the 1x1 conv + residual of the same
+                                            residual unit (residual_unit.py:78-81): the runner may launch both as one kernel
+                                            (split-f16 rows-in-LDS kernel; the intermediate then never goes to memory) */
 } adk_op_desc;
 
 /* rows of ring i = hist + max_frames * rate (arena rings). */
@@ -238,8 +245,9 @@ int adk_program_set_workgroups(adk_program* p, int32_t workgroups);
  * Ring cursors are kernel arguments, so a captured launch sequence is only valid for the cursor state it was captured in:
  * that state repeats with a short period when every ring length is a small multiple of its per-step advance
  * (max_frames * rate) -- the caller sizes the rings so by rounding `hist` up (audiodec_amd/program.py does); otherwise this
- * call fails and the program stays eager.  Only steps of exactly max_frames frames in a recognised phase replay; any other
- * step (short chunk, first step after reset, profiling) runs eagerly, results are identical either way.  The stream-K publish
+ * call fails and the program stays eager.  Only steps of exactly max_frames frames in a recognised phase, on a stream other than
+ * the legacy default stream (which cannot be captured), replay; any other step (short chunk, first step after reset,
+ * profiling) runs eagerly, results are identical either way.  The stream-K publish
  * flags are zeroed by a memset node at the head of each graph (their per-launch epochs are frozen by the capture). */
 int adk_program_set_graph(adk_program* p, int32_t enabled);
 int adk_program_graph_stats(const adk_program* p, int64_t* replays, int64_t* captures, int32_t* period);

@@ -46,7 +46,7 @@ def test_abi_version_and_struct_sizes(lib):
     assert C.sizeof(native.RingView) == 24
     assert C.sizeof(native.ConvDesc) == 80
     assert C.sizeof(native.RingDesc) == 24
-    assert C.sizeof(native.OpDesc) == 184
+    assert C.sizeof(native.OpDesc) == 184          # fuse_next took the tail padding
 
 
 def test_argument_validation_without_device(lib):

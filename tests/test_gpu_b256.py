@@ -57,12 +57,16 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
     names = {k for _, k, _, _ in kern}
     if split16:
         # the kernels bench.py's headline number is made of -- all of them are in the programs checked here
-        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_sk16<128x64>", "conv_sk16<64x64>", "conv_up16<64>"} <= names, names
+        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_rl16_unit<32>", "conv_rl16_unit<64>", "conv_sk16<128x64>", "conv_sk16<64x64>",
+                "conv_up16<64>"} <= names, names
         rl_taps = {(k, t) for _, k, t, _ in kern if k.startswith("conv_rl16")}
-        assert {("conv_rl16<32>", 1), ("conv_rl16<32>", 7), ("conv_rl16<32>", 11), ("conv_rl16<64>", 1),
-                ("conv_rl16<64>", 7), ("conv_rl16<64>", 11)} <= rl_taps, rl_taps
-        assert dict((n, k) for n, k, _, _ in kern)["upsamples.3"] == "conv_up16<64>"           # the north-star's named kernel
-        assert any(k.startswith("conv_rl16") and t == 1 and res for _, k, t, res in kern)       # 1x1 + residual in the rows kernel
+        assert {("conv_rl16_unit<32>", 7), ("conv_rl16<32>", 11), ("conv_rl16_unit<64>", 7), ("conv_rl16<64>", 11)} <= rl_taps, rl_taps
+        by_name = dict((n, k) for n, k, _, _ in kern)
+        assert by_name["upsamples.3"] == "conv_up16<64>"                                       # the north-star's named kernel
+        # the residual units of encoder blocks 0-1 run as ONE launch each (K7 conv + 1x1 + residual)
+        assert by_name["encoder.conv_blocks.0.res_units.0.conv1"] == "conv_rl16_unit<32>"
+        assert by_name["encoder.conv_blocks.0.res_units.0.conv2"] == "(fused into the previous op)"
+        assert by_name["encoder.conv_blocks.1.res_units.2.conv1"] == "conv_rl16_unit<64>"
     else:
         assert {"conv_rl<32>", "conv_rl<64>", "conv_sk<64x64>"} <= names, names
     # bench.py's inputs: stream s of batch j = synth_audio(SEED + j, s, HOP)
@@ -263,7 +267,9 @@ def test_graph_replay_is_bit_identical_to_eager(gpu, ckpt_root, split16):
         return idx, ad.decoder.decode(ad.rx_encoder.lookup(idx))
 
     pos = 0
-    with torch.no_grad():
+    side = torch.cuda.Stream(DEV)                                  # graphs are captured on a side stream (never on the legacy default one)
+    torch.cuda.synchronize()                                       # the warm-ups above ran on the default stream
+    with torch.no_grad(), torch.cuda.stream(side):
         for i in range(steps):
             frames = 1 if i in (17, 18, 19) else 2                 # three short steps: eager, and the phase is left for a while
             x = torch.from_numpy(audio[:, pos:pos + frames * hop])[:, None, :].to(DEV)
@@ -285,5 +291,37 @@ def test_graph_replay_is_bit_identical_to_eager(gpu, ckpt_root, split16):
     rep_e, cap_e, per_e = ad_g.tx_encoder._encoder().graph_stats()
     assert rep_e > 0 and cap_e <= per_e
     assert ad_e.decoder._decoder().graph_stats() == (0, 0, 0)
+    from audiodec_amd import native
+    assert native.device_flags() == 0
+
+
+@pytest.mark.parametrize("model,B,max_frames", [("vctk_sym", 200, 1), ("vctk_sym", 100, 2), ("vctk_v1", 256, 1)])
+def test_fused_residual_units_are_bit_identical(gpu, ckpt_root, model, B, max_frames):
+    """CausalResidualUnit.inference (residual_unit.py:78-81) as one launch (conv_rl16_kernel<..., FUSE>: K7 conv, act + split in
+    registers -> LDS, 1x1 conv + residual) against the same unit as two launches (ADK_FUSE=0): every output bit equal, for the
+    encoder's and the symmetric decoder's 32- / 64-channel blocks, 4- and 5-wave tilings."""
+    from audiodec_amd import program
+    hop = HOP
+    audio = np.stack([synth.synth_audio(77, s % 7, 3 * max_frames * hop) for s in range(B)])
+    old = program.FUSE_RES_UNITS
+    try:
+        program.FUSE_RES_UNITS = True
+        ad_f = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
+        program.FUSE_RES_UNITS = False
+        ad_u = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
+    finally:
+        program.FUSE_RES_UNITS = old
+    kf = [ad_f.tx_encoder._encoder().describe_op(i, max_frames) for i in range(ad_f.tx_encoder._encoder().n_ops)]
+    ku = [ad_u.tx_encoder._encoder().describe_op(i, max_frames) for i in range(ad_u.tx_encoder._encoder().n_ops)]
+    assert kf.count("conv_rl16_unit<32>") == 3 and kf.count("conv_rl16_unit<64>") == 3 and kf.count("(fused into the previous op)") == 6, kf
+    assert not any("unit" in k or "fused" in k for k in ku), ku
+    with torch.no_grad():
+        for i in range(3):
+            x = torch.from_numpy(audio[:, i * max_frames * hop:(i + 1) * max_frames * hop])[:, None, :].to(DEV)
+            zf, zu = ad_f.tx_encoder.encode(x), ad_u.tx_encoder.encode(x)
+            assert torch.equal(zf, zu), i
+            idx = ad_f.tx_encoder.quantize(zf)
+            yf = ad_f.decoder.decode(ad_f.rx_encoder.lookup(idx)); yu = ad_u.decoder.decode(ad_u.rx_encoder.lookup(idx))
+            assert torch.equal(yf, yu), i
     from audiodec_amd import native
     assert native.device_flags() == 0
