@@ -64,6 +64,8 @@ bool conv_up16_supported(const ConvArgs& a);        // streaming kernel of the l
 int launch_conv_up16(const ConvArgs& a, hipStream_t s);
 int conv_gk16_pick(const ConvArgs& a, bool force = false);              // big-tile split-f16 stream-K for the deep layers: 0 = not taken, 1 = 256x128, 2 = 128x256, 3 = 128x128
 int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws, bool force = false);
+bool conv_bk16_pick(const ConvArgs& a, bool force = false);          // register-staged 128x128 tiles (64x64 per wave) for the many-tile deep layers
+int launch_conv_bk16(const ConvArgs& a, hipStream_t s, Workspace& ws);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
 int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);

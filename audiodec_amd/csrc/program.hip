@@ -75,7 +75,7 @@ static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling stre
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP ||
-           impl == ADK_IMPL_SPLIT16_GK;
+           impl == ADK_IMPL_SPLIT16_GK || impl == ADK_IMPL_SPLIT16_BK;
 }
 static void read_env() {
     if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
@@ -104,6 +104,11 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
         if (impl == ADK_IMPL_SPLIT16_GK) return launch_conv_gk16(a, s, ws, true);
+        if (impl == ADK_IMPL_SPLIT16_BK) {
+            if (!conv_bk16_pick(a, true)) return fail(ADK_ERR_SHAPE, "conv: the 128x128 kernel needs cin_g % 32 == 0 and >= 128 output channels per group");
+            return launch_conv_bk16(a, s, ws);
+        }
+        if (impl == ADK_IMPL_SPLIT16 && conv_bk16_pick(a)) return launch_conv_bk16(a, s, ws);
         if (impl == ADK_IMPL_SPLIT16 && conv_gk16_pick(a)) return launch_conv_gk16(a, s, ws);
         return launch_conv_sk16(a, s, ws);
     }
@@ -128,6 +133,8 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
+        if ((impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_BK) && conv_mfma_supported(a) && conv_bk16_pick(a, impl == ADK_IMPL_SPLIT16_BK))
+            return "conv_bk16<128x128>";
         if ((impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_GK) && conv_mfma_supported(a)) {
             const int gk = conv_gk16_pick(a, impl == ADK_IMPL_SPLIT16_GK);
             if (gk) return gk == 1 ? "conv_gk16<256x128>" : (gk == 2 ? "conv_gk16<128x256>" : "conv_gk16<128x128>");
