@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM-side traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (CSV output).
+
+usage: pmc_summary.py <dir with *FETCH_SIZE*/ and *WRITE_SIZE*/ pass directories> <out.csv>
+FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of 16 B/lane streaming reads); values are KB per launch,
+averaged per (kernel, grid size)."""
+import collections, csv, glob, os, sys
+
+def load(d, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = (r["Kernel_Name"], int(r["Grid_Size"]))
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    return acc
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    fd = [d for d in glob.glob(os.path.join(root, "*FETCH_SIZE*")) if os.path.isdir(d)]
+    wd = [d for d in glob.glob(os.path.join(root, "*WRITE_SIZE*")) if os.path.isdir(d)]
+    f = load(fd[0], "FETCH_SIZE") if fd else {}
+    w = load(wd[0], "WRITE_SIZE") if wd else {}
+    rows = []
+    for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, [0, 1])[0])):
+        if not k[0].startswith("void adk::") and "adk" not in k[0]:
+            continue
+        fa = f.get(k, [0.0, 0]); wa = w.get(k, [0.0, 0])
+        fk = fa[0] / fa[1] if fa[1] else 0.0
+        wk = wa[0] / wa[1] if wa[1] else 0.0
+        name = k[0].replace("void adk::", "").split("(adk::")[0]
+        rows.append((name, k[1], max(fa[1], wa[1]), round(fk), round(2 * fk), round(wk)))
+    with open(out, "w") as fh:
+        fh.write("kernel,grid_threads,launches,FETCH_SIZE_KB_avg,FETCH_KB_x2_corrected,WRITE_SIZE_KB_avg\n")
+        for r in rows:
+            fh.write('"%s",%d,%d,%d,%d,%d\n' % r)
+    print(open(out).read())
+
+if __name__ == "__main__":
+    main()
