@@ -28,6 +28,8 @@ HOP = 300
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak; a split-f16 product sum issues 3 of them
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_TRAFFIC_FILE = "r2_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench (tools/run_r2k.sh)
+PMC_TRAFFIC_COMMIT = "82a09df"                 # the commit those passes were taken at
 
 
 def build_audiodec(root, device, streams, max_frames, sd_bcast=False):
@@ -155,7 +157,7 @@ def pmc_traffic(dom, split16):
     (grid = 512 workgroups).  PMC counters cannot be collected from inside this process; None when the file is absent."""
     import csv
     import re
-    path = os.path.join(ROOT, "profiles", "r1_pmc_split16_traffic.csv" if split16 else "r1_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE if split16 else "r1_pmc_summary.csv")
     m = re.match(r"conv_sk(16)?<(\d+)x(\d+)>", dom)
     if not os.path.exists(path) or not m:
         return None
@@ -207,7 +209,8 @@ def roofline_from(rows, streams, fps=1, split16=False):
             "algorithmic_bytes_per_launch": full_grid_bytes(rows, dom, streams, fps),
             "traffic_note": "both per launch, over the launches of this kernel that use the full 512-workgroup grid (the only ones the PMC "
                             "file can tell from B=1 / warm-up launches): traffic = FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
-                            "(profiles/r1_pmc_*), not collected live; algorithmic = input rows incl. history + weights + outputs (+ residual), once each",
+                            f"(profiles/{PMC_TRAFFIC_FILE}, captured at commit {PMC_TRAFFIC_COMMIT} with tools/run_r2k.sh; PMC counters cannot be read from inside the "
+                            "bench process), not collected live; algorithmic = input rows incl. history + weights + outputs (+ residual), once each",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
             "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
