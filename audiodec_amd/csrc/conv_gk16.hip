@@ -36,6 +36,9 @@ typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr float kGkLoScale = 2048.f, kGkLoInv = 1.f / 2048.f;
+#ifndef ADK_GK16_DBG
+#define ADK_GK16_DBG 0      // tuning experiments only: 1 = fragments used as read (no activation, no hi / lo conversion; results wrong)
+#endif
 constexpr int GK_KS = 32;          // K slice per stage: one tap x 32 channels
 constexpr int GK_NST = 3;          // LDS ring depth
 
@@ -298,6 +301,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) >= 8 ? 2 : 1) void conv_gk1
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const u32x4g u = rx[ks][2 * j], v = rx[ks][2 * j + 1];
+#if ADK_GK16_DBG & 1
+                Bh[j] = as_h(u); Bl[j] = as_h(v);      // what a pre-split ring (hi | lo f16 planes, same bytes) would cost
+                continue;
+#endif
                 const float x[8] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w),
                                     __uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 #pragma unroll

@@ -481,6 +481,9 @@ const Cfg kCfgs[6] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"
 int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
 int g_fixed_g = 0;         // persistent workgroups per launch when > 0 (ADK_CONV_G / adk_set_conv_workgroups), else 256 * g_occ
+int g_max_split = 5;       // most workgroups sharing one tile (ADK_CONV_MAX_SPLIT; 0 = no limit).  Measured (tools/run_r2s.sh):
+                           // 5 vs no limit at 256 streams: last strided conv 30.9 -> 18.3 us, first transposed conv 25.2 -> 18.9,
+                           // K10 strided 24.1 -> 19.3; at 1 stream the grouped K11 256-channel conv 28.3 -> 18.9, projector 19.9 -> 13.9
 int g_min_units = 2;       // minimum K chunks per workgroup (ADK_CONV_MIN_UNITS; 2 measured best at 256 streams)
 
 template <int WGM, int WGN, int NJ, bool SPLIT, int KD = 1>
@@ -510,6 +513,9 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     long long G = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, 256LL * g_occ) : (g_fixed_g > 0 ? g_fixed_g : 256LL * g_occ);
     const long long by_units = (sk.total + g_min_units - 1) / g_min_units;
     if (G > by_units) G = (by_units + 7) / 8 * 8;
+    // ... and never more than g_max_split workgroups on one tile: its owner adds the others' partial tiles one after the
+    // other, which is what a launch over few tiles (few streams, or the deepest layers) otherwise spends its time on
+    if (g_max_split > 0 && G > tiles * g_max_split) G = (tiles * g_max_split + 7) / 8 * 8;
     sk.G = (int)G;
     const size_t part_bytes = (size_t)sk.G * 256 * NJ * 16 * sizeof(float);
     if (!ws.ptr || part_bytes + (size_t)sk.G * sizeof(unsigned) > ws.bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
@@ -549,6 +555,7 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
     if (g_occ < 0) {
         const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2;
         e = getenv("ADK_CONV_MIN_UNITS"); if (e && atoi(e) >= 1) g_min_units = atoi(e);
+        e = getenv("ADK_CONV_MAX_SPLIT"); if (e && atoi(e) >= 0) g_max_split = atoi(e);
         e = getenv("ADK_CONV_G"); if (e && atoi(e) >= 8 && atoi(e) <= 256 * g_occ) g_fixed_g = atoi(e) / 8 * 8;
     }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);

@@ -427,15 +427,46 @@ bool conv_rl16_supported(const ConvArgs& a) {
     return true;
 }
 
-// AUTO (ADK_IMPL_SPLIT16): rows-in-LDS when one workgroup per (stream, group, time tile) fills the chip and a stream
-// contributes at least most of an n-tile; else the stream-K variant
+static bool rl16_few_streams() {                 // ADK_RL16_FEW=0 (tuning): the round-1 rule -- rows kernel only when >= 192 long tiles
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ADK_RL16_FEW"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
+// Time steps per workgroup.  0: the history does not fit.
+static int rl16_time_tile(const ConvArgs& a) {
+    const int rs = 4 * a.cin_g + 16;
+    const int span = (a.taps - 1) * a.dilation;
+    int tt = ((54000 / rs - span) / 32) * 32;
+    if (tt < 32) return 0;
+    const int nt32 = (a.t_out + 31) / 32;
+    if (tt >= a.t_out) tt = a.t_out;
+    // few streams: one n-tile per workgroup while that keeps the launch within one round of resident workgroups (3 per CU).
+    // Re-staging the history per tile costs nothing when most CUs would idle otherwise (measured, tools/run_r2q.sh: the
+    // 32-channel K7 conv at 1 / 32 / 64 streams 9.9 / 10.5 / 10.7 -> 6.4 / 7.1 / 8.5 us; stream-K takes 15 / 17 / 20 us)
+    if (rl16_few_streams() && nt32 > 1 && (long long)a.batch * nt32 * a.groups <= 768) tt = 32;
+    // one tile would cover the whole call: cut a long one (>= 8 n-tiles, e.g. the 300-step frame of the 32-channel
+    // layers) into two balanced halves -- twice the workgroups, two dispatch rounds whose load / matrix-core / store
+    // phases overlap instead of running in lockstep (measured 38.0 -> 34.2 us; shorter tiles lose to the re-staged history)
+    else if (tt >= a.t_out && nt32 >= 8) tt = ((nt32 + 1) / 2) * 32;
+    // ... and a short one whose (m-tile, n-tile pair) items would need two passes of the 4 waves (the 64 -> 32 transposed
+    // conv: 3 m-tiles x 2 pairs) when halving it leaves at most one item per wave
+    else if (tt >= a.t_out && nt32 >= 4 && (a.cout_g / 32) * ((nt32 + 1) / 2) > 4 && (a.cout_g / 32) * (((nt32 + 1) / 2 + 1) / 2) <= 4)
+        tt = ((nt32 + 1) / 2) * 32;
+    static int tt_env = -1;                                                  // tuning: shorter time tiles (more, smaller workgroups)
+    if (tt_env < 0) { const char* e = getenv("ADK_RL16_TT"); tt_env = e ? atoi(e) : 0; }
+    if (tt_env >= 32 && tt_env < tt) tt = tt_env / 32 * 32;
+    return tt;
+}
+
+// AUTO (ADK_IMPL_SPLIT16): rows-in-LDS wherever the layer qualifies and a call brings at least most of an n-tile per
+// stream (measured faster than the stream-K variant at every stream count from 1 to 256, tools/run_r2q.sh)
 bool conv_rl16_preferred(const ConvArgs& a) {
     if (!conv_rl16_supported(a) || a.t_out < 24) return false;
-    const int rs = 4 * a.cin_g + 16;
-    const int tt = ((54000 / rs - (a.taps - 1) * a.dilation) / 32) * 32;
-    if (tt < 32) return false;
-    const long long tiles = tt >= a.t_out ? 1 : (a.t_out + tt - 1) / tt;
-    return (long long)a.batch * tiles * a.groups >= 192;
+    const int tt = rl16_time_tile(a);
+    if (tt <= 0) return false;
+    if (!rl16_few_streams()) return (long long)a.batch * ((a.t_out + tt - 1) / tt) * a.groups >= 192;
+    return true;
 }
 
 namespace {
@@ -482,22 +513,8 @@ int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
 
 int launch_conv_rl16(const ConvArgs& a, hipStream_t s) {
     if (a.n_total == 0) return ADK_OK;
-    const int rs = 4 * a.cin_g + 16;
-    const int span = (a.taps - 1) * a.dilation;
-    int tt = ((54000 / rs - span) / 32) * 32;
-    if (tt < 32) return fail(ADK_ERR_SHAPE, "conv: history too long for the rows-in-LDS kernel");
-    if (tt >= a.t_out) tt = a.t_out;
-    // one tile would cover the whole call: cut a long one (>= 8 n-tiles, e.g. the 300-step frame of the 32-channel
-    // layers) into two balanced halves -- twice the workgroups, two dispatch rounds whose load / matrix-core / store
-    // phases overlap instead of running in lockstep (measured 38.0 -> 34.2 us; shorter tiles lose to the re-staged history)
-    if (tt >= a.t_out && (a.t_out + 31) / 32 >= 8) tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
-    // ... and a short one whose (m-tile, n-tile pair) items would need two passes of the 4 waves (the 64 -> 32 transposed
-    // conv: 3 m-tiles x 2 pairs) when halving it leaves at most one item per wave
-    else if (tt >= a.t_out && (a.t_out + 31) / 32 >= 4 && (a.cout_g / 32) * (((a.t_out + 31) / 32 + 1) / 2) > 4 &&
-             (a.cout_g / 32) * ((((a.t_out + 31) / 32 + 1) / 2 + 1) / 2) <= 4)
-        tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
-    { static int tt_env = -1; if (tt_env < 0) { const char* e = getenv("ADK_RL16_TT"); tt_env = e ? atoi(e) : 0; }
-      if (tt_env >= 32 && tt_env < tt) tt = tt_env / 32 * 32; }          // tuning: shorter time tiles (more, smaller workgroups)
+    const int tt = rl16_time_tile(a);
+    if (tt <= 0) return fail(ADK_ERR_SHAPE, "conv: history too long for the rows-in-LDS kernel");
     // work items of a workgroup = m-tiles x pairs of n-tiles; 5 waves when that is a multiple of 5 (the 300-step
     // frame of a 32-channel layer: 10 n-tiles), else 4
     const int n_tiles = (std::min(tt, a.t_out) + 31) / 32;
@@ -558,15 +575,8 @@ int launch_conv_rl16_fused(const ConvArgs& a, const ConvArgs& a2, hipStream_t s)
     if (a.n_total == 0) return ADK_OK;
     if (!conv_rl16_fusable(a, a2)) return ADK_ERR_STATE;
     // the same time tiling as launch_conv_rl16 (so that phase 1 is the same launch), then: at most one item per wave
-    const int rs = 4 * a.cin_g + 16;
-    const int span = (a.taps - 1) * a.dilation;
-    int tt = ((54000 / rs - span) / 32) * 32;
-    if (tt < 32) return ADK_ERR_STATE;
-    if (tt >= a.t_out) tt = a.t_out;
-    if (tt >= a.t_out && (a.t_out + 31) / 32 >= 8) tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
-    else if (tt >= a.t_out && (a.t_out + 31) / 32 >= 4 && (a.cout_g / 32) * (((a.t_out + 31) / 32 + 1) / 2) > 4 &&
-             (a.cout_g / 32) * ((((a.t_out + 31) / 32 + 1) / 2 + 1) / 2) <= 4)
-        tt = (((a.t_out + 31) / 32 + 1) / 2) * 32;
+    const int tt = rl16_time_tile(a);
+    if (tt <= 0) return ADK_ERR_STATE;
     const int n_tiles = (std::min(tt, a.t_out) + 31) / 32;
     const int items = (a.cout_g / 32) * ((n_tiles + 1) / 2);
     if (items > 5) return ADK_ERR_STATE;

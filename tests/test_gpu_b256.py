@@ -295,11 +295,13 @@ def test_graph_replay_is_bit_identical_to_eager(gpu, ckpt_root, split16):
     assert native.device_flags() == 0
 
 
-@pytest.mark.parametrize("model,B,max_frames", [("vctk_sym", 200, 1), ("vctk_sym", 100, 2), ("vctk_v1", 256, 1)])
+@pytest.mark.parametrize("model,B,max_frames", [("vctk_sym", 200, 1), ("vctk_sym", 100, 2), ("vctk_v1", 256, 1),
+                                                ("vctk_sym", 1, 1), ("vctk_sym", 3, 2), ("vctk_v1", 24, 1)])
 def test_fused_residual_units_are_bit_identical(gpu, ckpt_root, model, B, max_frames):
     """CausalResidualUnit.inference (residual_unit.py:78-81) as one launch (conv_rl16_kernel<..., FUSE>: K7 conv, act + split in
     registers -> LDS, 1x1 conv + residual) against the same unit as two launches (ADK_FUSE=0): every output bit equal, for the
-    encoder's and the symmetric decoder's 32- / 64-channel blocks, 4- and 5-wave tilings."""
+    encoder's and the symmetric decoder's 32- / 64-channel blocks, 4- and 5-wave tilings; at few streams the time tiles are
+    one n-tile long (ragged last tile at 300 steps)."""
     from audiodec_amd import program
     hop = HOP
     audio = np.stack([synth.synth_audio(77, s % 7, 3 * max_frames * hop) for s in range(B)])

@@ -223,7 +223,8 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
 
 
 @pytest.mark.parametrize("model,B,frames,split16", [("vctk_v1", 16, [1, 1, 2, 1], False), ("vctk_sym", 33, [1, 3], False),
-                                                    ("vctk_v1", 16, [1, 1, 2, 1], True), ("vctk_sym", 33, [1, 3], True)])
+                                                    ("vctk_v1", 16, [1, 1, 2, 1], True), ("vctk_sym", 33, [1, 3], True),
+                                                    ("vctk_v1", 64, [1, 1], True)])
 def test_batched_streams_match_oracle(gpu, ckpt_root, model, B, frames, split16):
     """B streams in one object == the B-stream oracle (B independent reference instances)."""
     seed = 4242
