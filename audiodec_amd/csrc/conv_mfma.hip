@@ -64,7 +64,10 @@ struct SkArgs {
     float* ws;            // partial-tile workspace: [G][256 threads][NJ*16] floats
     unsigned* flags;      // [G] publish flags: flags[r] == epoch <=> range r's head partial is in ws
     unsigned epoch;       // unique per launch on this workspace (never 0)
-    int G;                // persistent workgroups (multiple of 8)
+    int G;                // persistent workgroups (ranges); the grid is 8 * ceil(G / 8) blocks
+    int split;            // > 0: tile-aligned ranges, `split` workgroups per tile (range r = tile r / split, part r % split)
+    int tpw;              // > 0: tile-aligned ranges, `tpw` whole tiles per workgroup;  both 0: total / G units each, wherever that cuts
+    int tiles;
     int m_tiles, n_tiles, nchunks;
     int cpt;              // 32-channel blocks per tap = cin_g / 32
     int kgroups;          // 8-k fragments per 32-row m-tile, K zero-padded to a multiple of 64
@@ -83,7 +86,19 @@ __device__ __forceinline__ float act_in_apply(float x, float slope) {
     return x;
 }
 
-__device__ __forceinline__ long long sk_u0(int r, const SkArgs& sk) { return (long long)r * sk.total / sk.G; }
+// first work unit of range r (r = G: one past the last)
+__device__ __forceinline__ long long sk_u0(int r, const SkArgs& sk) {
+    if (sk.split > 0) {
+        const int t = r / sk.split, p = r - t * sk.split;
+        return (long long)t * sk.nchunks + (p * sk.nchunks) / sk.split;
+    }
+    if (sk.tpw > 0) {
+        long long t = (long long)r * sk.tpw;
+        if (t > sk.tiles) t = sk.tiles;
+        return t * sk.nchunks;
+    }
+    return (long long)r * sk.total / sk.G;
+}
 
 // Epilogue for one wave's 32 x (32*NJ) accumulator block: bias, residual, output activation, store.
 // Lane holds column n = n0w + 32*j + (lane&31) and rows ml0 + 8*qd + 4*(lane>>5) + {0..3}.
@@ -189,7 +204,9 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     const int half = quad >> 3;                       // which 32-channel sub-chunk (0 .. 2*KD-1) this thread stages
 
     // XCD-contiguous range of work units
-    const int r = (int)(blockIdx.x & 7) * (sk.G >> 3) + (int)(blockIdx.x >> 3);
+    const int per_xcd = (sk.G + 7) >> 3;
+    const int r = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (r >= sk.G) return;
     const long long u0 = sk_u0(r, sk), u1 = sk_u0(r + 1, sk);
     if (u0 >= u1) return;
 
@@ -481,6 +498,7 @@ const Cfg kCfgs[6] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"
 int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
 int g_fixed_g = 0;         // persistent workgroups per launch when > 0 (ADK_CONV_G / adk_set_conv_workgroups), else 256 * g_occ
+int g_aligned = 1;         // tile-aligned stream-K ranges where the rule in launch_cfg applies (ADK_CONV_ALIGNED=0: never)
 int g_max_split = 5;       // most workgroups sharing one tile (ADK_CONV_MAX_SPLIT; 0 = no limit).  Measured (tools/run_r2s.sh):
                            // 5 vs no limit at 256 streams: last strided conv 30.9 -> 18.3 us, first transposed conv 25.2 -> 18.9,
                            // K10 strided 24.1 -> 19.3; at 1 stream the grouped K11 256-channel conv 28.3 -> 18.9, projector 19.9 -> 13.9
@@ -510,12 +528,30 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     sk.total = tiles * sk.nchunks;
     // persistent workgroups: 256 CUs x occupancy, but never fewer than g_min_units chunks per workgroup
     // (each one pays a fixed prologue/epilogue, and every cut of a tile costs a partial round trip)
-    long long G = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, 256LL * g_occ) : (g_fixed_g > 0 ? g_fixed_g : 256LL * g_occ);
+    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, 256LL * g_occ) : (g_fixed_g > 0 ? g_fixed_g : 256LL * g_occ);
+    long long G = cap;
     const long long by_units = (sk.total + g_min_units - 1) / g_min_units;
     if (G > by_units) G = (by_units + 7) / 8 * 8;
     // ... and never more than g_max_split workgroups on one tile: its owner adds the others' partial tiles one after the
     // other, which is what a launch over few tiles (few streams, or the deepest layers) otherwise spends its time on
     if (g_max_split > 0 && G > tiles * g_max_split) G = (tiles * g_max_split + 7) / 8 * 8;
+    sk.split = 0; sk.tpw = 0; sk.tiles = (int)tiles;
+    // Tile-aligned ranges (measured, tools/run_r2z.sh at 256 streams: a range that straddles two tiles pays two partial round
+    // trips -- 200-tile 1x1 / strided / transposed convs 20.7 -> 10.8 / 13.0 / 13.4 us with one whole tile per workgroup, the
+    // grouped K11 256-channel conv 50.8 -> 44.3 us with exact halves).  Short K (<= 8 chunks): whole tiles, as many per
+    // workgroup as it takes.  Long K: an even split when >= 2 workgroups per tile fit (one workgroup per CU first, then
+    // ~6 chunks each); a long-K layer with more tiles than that keeps the balanced split above.
+    if (g_aligned && tiles < (1 << 20)) {
+        const int ms = g_max_split > 0 ? g_max_split : 5;
+        if (tiles > cap) {
+            if (sk.nchunks <= 8) { sk.tpw = (int)((tiles + cap - 1) / cap); G = (tiles + sk.tpw - 1) / sk.tpw; }
+        } else {
+            long long sp = std::max<long long>(std::min<long long>(ms, 256 / tiles), std::min<long long>(ms, sk.nchunks / 6));
+            if (sp < 1) sp = 1;
+            while (sp > 1 && (tiles * sp > cap || sk.nchunks / sp < g_min_units)) --sp;
+            if (sp > 1 || sk.nchunks < 12) { sk.split = (int)sp; G = tiles * sp; }
+        }
+    }
     sk.G = (int)G;
     const size_t part_bytes = (size_t)sk.G * 256 * NJ * 16 * sizeof(float);
     if (!ws.ptr || part_bytes + (size_t)sk.G * sizeof(unsigned) > ws.bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
@@ -535,12 +571,13 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
             attr_set = true;
         }
     }
+    const unsigned grid = (unsigned)((sk.G + 7) / 8 * 8);
     if (a.act_in == ADK_ACT_ELU)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), dim3(grid), dim3(256), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_LEAKY)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), dim3(grid), dim3(256), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_NONE)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT, KD>), dim3(sk.G), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT, KD>), dim3(grid), dim3(256), lds, s, a, sk);
     else
         return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
     ADK_HIP_CHECK(hipGetLastError());
@@ -556,6 +593,7 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
         const char* e = getenv("ADK_CONV_OCC"); g_occ = e ? atoi(e) : 2; if (g_occ < 1 || g_occ > 4) g_occ = 2;
         e = getenv("ADK_CONV_MIN_UNITS"); if (e && atoi(e) >= 1) g_min_units = atoi(e);
         e = getenv("ADK_CONV_MAX_SPLIT"); if (e && atoi(e) >= 0) g_max_split = atoi(e);
+        e = getenv("ADK_CONV_ALIGNED"); if (e) g_aligned = atoi(e) != 0;
         e = getenv("ADK_CONV_G"); if (e && atoi(e) >= 8 && atoi(e) <= 256 * g_occ) g_fixed_g = atoi(e) / 8 * 8;
     }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);

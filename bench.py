@@ -70,10 +70,13 @@ class TxRxPipeline:
         self.n_dec = getattr(ad.decoder, "stages", 1)
         self.two = self.n_dec >= 2
         self.s_more = [torch.cuda.Stream(dev) for _ in range(self.n_dec - 1)]
-        # several programs run concurrently: each stream-K launch assumes half the chip's workgroup slots instead of all
-        # of them (measured at 3 programs: 256 persistent workgroups 210 k frames/s, 384: 203 k, 512: 189 k)
-        if self.two and getattr(ad.decoder, "split16", False):     # (the exact-f32 kernels are matrix-core-bound: whole chip is better)
-            wg = int(os.environ.get("ADK_BENCH_WORKGROUPS", "256"))
+        # ADK_BENCH_WORKGROUPS (tuning): cap on the persistent workgroups of a stream-K launch.  Round 1 ran the three
+        # concurrent programs with 256 (half the chip's slots each: 210 k frames/s vs 189 k at 512); with tile-aligned ranges
+        # (round 2) the library default -- up to 512, e.g. exact halves of the 240 tiles of a stage-0 grouped conv -- is as fast
+        # and cuts the batch latency (tools/run_r3b.sh: 256 / 384 / 480 / 512 -> 212.3 / 213.5 / 214.2 / 213.0 k frames/s,
+        # 1.86 / 1.81 / 1.73 / 1.71 ms), so nothing is set here any more
+        wg = int(os.environ.get("ADK_BENCH_WORKGROUPS", "0"))
+        if wg > 0 and self.two and getattr(ad.decoder, "split16", False):
             ad.tx_encoder.set_workgroups(wg)
             ad.decoder.set_workgroups(wg)
 

@@ -50,9 +50,8 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
         else:
             os.environ["ADK_VOCODER_STAGES"] = old
     assert ad.decoder.stages == 2
-    pipe = bench.TxRxPipeline(ad, DEV)                         # sets the 256-workgroup share exactly as bench.py does
-    if split16:
-        assert ad.decoder.workgroups == 256 and ad.tx_encoder.workgroups == 256
+    pipe = bench.TxRxPipeline(ad, DEV)                         # streams / workgroup share exactly as bench.py sets them up
+    assert ad.decoder.workgroups == 0 and ad.tx_encoder.workgroups == 0      # (library default since round 2: no cap)
     kern = _program_kernels(ad)
     names = {k for _, k, _, _ in kern}
     if split16:
