@@ -28,7 +28,9 @@ HOP = 300
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak; a split-f16 product sum issues 3 of them
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_MARKER_N = 7654321                         # --pmc-markers: element count of the marker launches
 PMC_TRAFFIC_FILE = "r2_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench (tools/run_r2k.sh)
+PMC_TRAFFIC_SCRIPT = "tools/run_r2k.sh"
 PMC_TRAFFIC_COMMIT = "82a09df"                 # the commit those passes were taken at
 
 
@@ -156,43 +158,30 @@ def op_profile(ad, xs, streams, n_steps, fps=1):
 
 def pmc_traffic(dom, split16):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads, + WRITE_SIZE), averaged over its 256-stream launches
-    (grid = 512 workgroups).  PMC counters cannot be collected from inside this process; None when the file is absent."""
+    MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads, + WRITE_SIZE), averaged over ALL its launches between the
+    two --pmc-markers of those passes (= the timed steps of this same bench at 256 streams; tools/pmc_summary.py).
+    PMC counters cannot be collected from inside this process; None when the file is absent."""
     import csv
     import re
-    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE if split16 else "r1_pmc_summary.csv")
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     m = re.match(r"conv_sk(16)?<(\d+)x(\d+)>", dom)
-    if not os.path.exists(path) or not m:
+    if not os.path.exists(path) or not m or not split16:
         return None
     cfg = {"64x64": "<2, 2, 1,", "128x64": "<4, 1, 2,", "32x128": "<1, 4, 1,"}.get(f"{m.group(2)}x{m.group(3)}")
     if cfg is None:
         return None
     num = den = 0.0
-    for r in csv.DictReader(open(path)):
-        if "conv_sk_kernel" + cfg in r["kernel"] and int(r["grid_threads"]) == 131072 and (("true" in r["kernel"]) == bool(split16)):
+    for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):
+        if "conv_sk_kernel" + cfg in r["kernel"] and "true" in r["kernel"]:
             n = float(r["launches"])
             num += n * (float(r["FETCH_KB_x2_corrected"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
             den += n
     return round(num / den) if den else None
 
 
-def full_grid_bytes(rows, dom, streams, fps):
-    """Mean compulsory bytes over the launches of kernel `dom` whose stream-K grid is the full 512 workgroups
-    (G = min(512, ceil(tiles * chunks / 2)), conv_mfma.hip launch_cfg)."""
-    import re
-    m = re.match(r"conv_sk(16)?<(\d+)x(\d+)>", dom)
-    if not m:
-        return None
-    bm, bn = int(m.group(2)), int(m.group(3))
-    sel = []
-    for r in rows:
-        if r["kernel"] != dom or r["op"].kind != 0:
-            continue
-        c = r["op"].conv
-        n = streams * r["op"].rate_out * fps
-        units = -(-c.cout_g // bm) * -(-n // bn) * c.groups * -(-(c.taps * c.cin_g) // 64)
-        if (units + 1) // 2 >= 512:
-            sel.append(r["bytes"])
+def mean_launch_bytes(rows, dom):
+    """Mean compulsory bytes per launch over the launches of kernel `dom` in one step (the launches pmc_traffic averages over)."""
+    sel = [r["bytes"] for r in rows if r["kernel"] == dom and r["op"].kind == 0]
     return round(sum(sel) / len(sel)) if sel else None
 
 
@@ -209,11 +198,12 @@ def roofline_from(rows, streams, fps=1, split16=False):
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom, split16),
-            "algorithmic_bytes_per_launch": full_grid_bytes(rows, dom, streams, fps),
-            "traffic_note": "both per launch, over the launches of this kernel that use the full 512-workgroup grid (the only ones the PMC "
-                            "file can tell from B=1 / warm-up launches): traffic = FETCH_SIZE x2 + WRITE_SIZE from the committed PMC passes "
-                            f"(profiles/{PMC_TRAFFIC_FILE}, captured at commit {PMC_TRAFFIC_COMMIT} with tools/run_r2k.sh; PMC counters cannot be read from inside the "
-                            "bench process), not collected live; algorithmic = input rows incl. history + weights + outputs (+ residual), once each",
+            "algorithmic_bytes_per_launch": mean_launch_bytes(rows, dom),
+            "traffic_note": "both are means per launch over all launches of this kernel in the timed steps: traffic = FETCH_SIZE x2 + "
+                            f"WRITE_SIZE from the committed PMC passes over this bench (profiles/{PMC_TRAFFIC_FILE}, captured at commit "
+                            f"{PMC_TRAFFIC_COMMIT} with {PMC_TRAFFIC_SCRIPT}, steady-state launches picked out by --pmc-markers; PMC counters cannot "
+                            "be read from inside the bench process), not collected live; algorithmic = input rows incl. history + weights + "
+                            "outputs (+ residual), once each",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
             "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
@@ -487,6 +477,10 @@ def main():
                          "third HIP stream (default); or explicit cut points, e.g. 1,2 = three programs on three streams")
     ap.add_argument("--graph", choices=("0", "1"), default=os.environ.get("ADK_BENCH_GRAPH", "0"),
                     help="1: replay each program's steady state as HIP graphs (adk_program_set_graph); results are bit-identical")
+    ap.add_argument("--pmc-markers", action="store_true",
+                    help="launch a recognisable ATen kernel (arange of PMC_MARKER_N elements) just before and just after the timed "
+                         "steps, so that tools/pmc_summary.py can tell the steady-state launches of a rocprofv3 --pmc pass from "
+                         "model loading, warm-up and the single-stream legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-cfg1", action="store_true", help="skip BASELINE config 1 (file round trip) on the host CPU")
     ap.add_argument("--no-self-check", action="store_true", help="skip the parity check of the timed configuration against the CPU oracle")
@@ -575,6 +569,8 @@ def main():
         if pipe:
             pipe.exit()
         sync_all()
+        if args.pmc_markers:                       # outside the timed region: see tools/pmc_summary.py
+            torch.arange(PMC_MARKER_N, device=dev); torch.cuda.synchronize()
         t0 = time.perf_counter()
         if pipe:
             pipe.enter()
@@ -584,6 +580,8 @@ def main():
             pipe.exit()
         sync_all()
         elapsed = time.perf_counter() - t0
+        if args.pmc_markers:
+            torch.arange(PMC_MARKER_N, device=dev); torch.cuda.synchronize()
     elapsed = shard.max_over_ranks(elapsed, coll_dev)
     frames = world * B * args.steps * FPS
     ms_per_step = 1e3 * elapsed / args.steps

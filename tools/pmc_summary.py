@@ -2,15 +2,31 @@
 """Per-kernel HBM-side traffic from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (CSV output).
 
 usage: pmc_summary.py <dir with *FETCH_SIZE*/ and *WRITE_SIZE*/ pass directories> <out.csv>
+With `bench.py --pmc-markers` only the launches of the timed steps are counted (see load()).
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it reports half the bytes of 16 B/lane streaming reads); values are KB per launch,
 averaged per (kernel, grid size)."""
 import collections, csv, glob, os, sys
 
+MARKERS = [0, 0]        # passes in which the two bench.py --pmc-markers launches were found / passes read
+
+
 def load(d, counter):
+    """(kernel, grid) -> [sum, launches] over the dispatches BETWEEN the two marker launches of `bench.py --pmc-markers` (the
+    largest-grid `arange` kernel, exactly twice) when they are there, else over all dispatches of the pass."""
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
+        rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+        lo, hi = -1, 1 << 62
+        ar = [r for r in rows if "arange" in r["Kernel_Name"]]
+        MARKERS[1] += 1
+        if ar:
+            g = max(int(r["Grid_Size"]) for r in ar)
+            ids = sorted(int(r["Dispatch_Id"]) for r in ar if int(r["Grid_Size"]) == g)
+            if len(ids) == 2 and g >= 1 << 16:
+                lo, hi = ids
+                MARKERS[0] += 1
+        for r in rows:
+            if not lo < int(r["Dispatch_Id"]) < hi:
                 continue
             k = (r["Kernel_Name"], int(r["Grid_Size"]))
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
@@ -32,6 +48,8 @@ def main():
         name = k[0].replace("void adk::", "").split("(adk::")[0]
         rows.append((name, k[1], max(fa[1], wa[1]), round(fk), round(2 * fk), round(wk)))
     with open(out, "w") as fh:
+        fh.write("# region: %s\n" % ("launches between the two bench.py --pmc-markers (the timed steps)" if MARKERS[0] == MARKERS[1] and MARKERS[1]
+                                     else "ALL launches of the passes (markers not found in every pass)"))
         fh.write("kernel,grid_threads,launches,FETCH_SIZE_KB_avg,FETCH_KB_x2_corrected,WRITE_SIZE_KB_avg\n")
         for r in rows:
             fh.write('"%s",%d,%d,%d,%d,%d\n' % r)
