@@ -46,12 +46,32 @@
 // error analysis.
 #include "adk_common.h"
 #include <cstdlib>
+#include <type_traits>
 
+#ifndef ADK_SK_SC1_READ
+#define ADK_SK_SC1_READ 1   // 1: partial tiles read with sc1 loads, no acquire fence; 0: plain loads behind an agent-scope acquire
+#endif
+#ifndef ADK_SK_OWNER_LATE
+#define ADK_SK_OWNER_LATE 1 // 1: with two workgroups per tile, the later-dispatched blocks of an XCD take the owner halves
+#endif
 #ifndef ADK_SK16_DBG
 #define ADK_SK16_DBG 0      // tuning experiments only: 1 = lo part not computed, 2 = no input activation
 #endif
 
 namespace adk {
+
+#if ADK_SK16_DBG & 32
+// per-workgroup wall-clock stamps (s_memrealtime, 100 MHz): kernel entry, loop entry, loop exit, kernel exit of wave 0
+__device__ unsigned long long g_sk_wg_trace[512 * 4];
+#endif
+#if ADK_SK16_DBG & 16
+// timeline of one workgroup's wave 0 (s_memtime at fixed points of every iteration): tools/kbench prints it (adk_debug_sk_trace)
+__device__ unsigned long long g_sk_trace[64 * 8];
+#define SK_STAMP(slot) do { if (trace_on && it < 64) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                            __builtin_amdgcn_sched_barrier(0); if (lane == 0) trace_lds[it * 8 + (slot)] = t_; } } while (0)
+#else
+#define SK_STAMP(slot) do { } while (0)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
@@ -66,6 +86,7 @@ struct SkArgs {
     unsigned epoch;       // unique per launch on this workspace (never 0)
     int G;                // persistent workgroups (ranges); the grid is 8 * ceil(G / 8) blocks
     int split;            // > 0: tile-aligned ranges, `split` workgroups per tile (range r = tile r / split, part r % split)
+    int owner_chunks;     // split == 2: chunks of a tile that its owner (first half) takes
     int tpw;              // > 0: tile-aligned ranges, `tpw` whole tiles per workgroup;  both 0: total / G units each, wherever that cuts
     int tiles;
     int m_tiles, n_tiles, nchunks;
@@ -90,6 +111,7 @@ __device__ __forceinline__ float act_in_apply(float x, float slope) {
 __device__ __forceinline__ long long sk_u0(int r, const SkArgs& sk) {
     if (sk.split > 0) {
         const int t = r / sk.split, p = r - t * sk.split;
+        if (sk.split == 2) return (long long)t * sk.nchunks + (p ? sk.owner_chunks : 0);
         return (long long)t * sk.nchunks + (p * sk.nchunks) / sk.split;
     }
     if (sk.tpw > 0) {
@@ -184,15 +206,19 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
 // KD = K-chunk depth in units of 64 (1: 64-deep, 2: 128-deep).  The split-f16 variant spends so little time in the
 // matrix cores per 64 k that the per-iteration costs (barrier, address update, exposed load latency) dominate: KD = 2
 // puts twice the bytes in flight per iteration and halves the iteration count.
+// WGM * WGN = 8 (512 threads, one workgroup per CU -- still 8 waves per CU): the 128 x 128 tile of the split variant, half the
+// operand bytes per MFMA of the 64 x 64 tile at the same number of waves in flight.
 template <int WGM, int WGN, int NJ, int ACT, bool SPLIT, int KD>
-__global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) {
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv_sk_kernel(ConvArgs a, SkArgs sk) {
+    constexpr int NT = 64 * WGM * WGN;                // threads per workgroup
     constexpr int BN = 32 * NJ * WGN;
     constexpr int KCC = KC * KD;                      // chunk depth
     constexpr int LDK = KCC + 4;                      // padded LDS row stride (floats); 68 and 132 are both = 4 mod 64
     constexpr int QPC = 16 * KD;                      // 16-byte pieces per staged column
-    constexpr int CPR = 256 / QPC;                    // columns staged per round
+    constexpr int CPR = NT / QPC;                     // columns staged per round
     constexpr int RB = BN / CPR;                      // staging rounds
-    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
+    static_assert(BN % CPR == 0, "staging rounds");
     static_assert(SPLIT || KD == 1, "the exact-f32 variant keeps 64-deep chunks");
     extern __shared__ __attribute__((aligned(16))) float Bs[];   // [2][BN*LDK]
 
@@ -205,8 +231,21 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
 
     // XCD-contiguous range of work units
     const int per_xcd = (sk.G + 7) >> 3;
-    const int r = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    int r = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+#if ADK_SK_OWNER_LATE
+    // Two workgroups per tile, two per CU: the second workgroup placed on a CU runs ~20 % slower than the first (per-workgroup
+    // wall clocks, profiles/r2_sk16_timeline.md), and the owner of a tile has to wait for the other half anyway.  Blocks are
+    // dispatched in index order, so let the first half of an XCD's blocks take the contributor halves (odd ranges) and the second
+    // half the owner halves: the partial tile is there long before its owner asks for it.
+    if (sk.split == 2 && !(per_xcd & 1) && sk.G == 8 * per_xcd) {
+        const int j = (int)(blockIdx.x >> 3), hp = per_xcd >> 1;
+        r = (int)(blockIdx.x & 7) * per_xcd + (j < hp ? 2 * j + 1 : 2 * (j - hp));
+    }
+#endif
     if (r >= sk.G) return;
+#if ADK_SK16_DBG & 32
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const long long u0 = sk_u0(r, sk), u1 = sk_u0(r + 1, sk);
     if (u0 >= u1) return;
 
@@ -218,10 +257,9 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
     const unsigned lane16 = (unsigned)lane * 16u;
     constexpr unsigned OOB = 0x80000000u;
 
-    // ---- staging state: describes the NEXT chunk to be loaded ----
+    // ---- activation staging state: describes the NEXT chunk whose X columns are to be loaded (XPD chunks ahead of the MFMAs) ----
     int s_tile, s_kc;                                  // wave-uniform
     int s_g = 0, s_mt = 0, s_nt = 0;
-    unsigned s_wbase = 0;                              // byte offset of this wave's fragment stream (OOB if none)
     int t_tap, t_cblk;                                 // per thread: tap / 32-channel block of ITS half-chunk
     unsigned colb[RB], rowb[RB];                       // per staged column: stream+channel base, ring row (tap applied)
 
@@ -244,8 +282,6 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
             rowb[rr] = rbv;
             colb[rr] = n < a.n_total ? ((unsigned)b * ring_bytes + (unsigned)(a.in_choff + s_g * a.in_gstride + 4 * (quad & 7)) * 4u) : OOB;
         }
-        const int mtile32 = s_mt * WGM + wm;           // 32-row fragment tile inside the group
-        s_wbase = mtile32 < sk.mt32_per_g ? (unsigned)((s_g * sk.mt32_per_g + mtile32) * sk.kgroups) * 1024u : 0xfff00000u;
     };
     auto stage_advance = [&]() {                       // staged chunk -> next chunk (maybe next tile)
         ++s_kc;
@@ -261,25 +297,50 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
             }
         }
     };
+    // ---- weight stream state: the NEXT chunk whose fragments are to be loaded (always one chunk ahead) ----
+    int w_tile, w_kc;
+    unsigned w_base = 0;                               // byte offset of this wave's fragment stream (out of bounds if it has none)
+    auto w_set = [&](int tile, int kc0) {
+        int g, mt, nt;
+        sk_tile_coords(tile, sk, g, mt, nt);
+        w_tile = tile; w_kc = kc0;
+        const int mtile32 = mt * WGM + wm;             // 32-row fragment tile inside the group
+        w_base = mtile32 < sk.mt32_per_g ? (unsigned)((g * sk.mt32_per_g + mtile32) * sk.kgroups) * 1024u : 0xfff00000u;
+    };
+    auto w_advance = [&]() { if (++w_kc == sk.nchunks) w_set(w_tile + 1, 0); };
 
-    float4 rb[RB];
-    float4 a_nxt[8 * KD];
-    auto gload = [&]() {
-        const bool k_ok = t_tap < a.taps;              // false on the zero-padded K tail
+    // Two register sets for each operand, used alternately by even and odd iterations (the loop below is unrolled by two with
+    // the roles swapped): nothing is ever copied, so a load is only waited for where its data is consumed -- a weight
+    // fragment at the MFMAs of the NEXT iteration, an activation piece when it is converted into LDS.  (Round 1 shifted
+    // `next` into `current` registers at the end of every iteration, which made every iteration end in s_waitcnt vmcnt(0).)
+    // XPD = 2 (split variant, 64-deep chunks): the activation loads run TWO chunks ahead -- issued at the top of iteration i,
+    // converted at the bottom of iteration i + 1 -- so they, too, have a whole iteration to land.
+    constexpr int XPD = (SPLIT && KD == 1 && NJ <= 2) ? 2 : 1;
+#ifndef ADK_SK16_ILV
+#define ADK_SK16_ILV 1      // 1: loads, MFMAs and conversion of an iteration interleaved in a pinned order (0: three phases)
+#endif
+    constexpr bool ILV = XPD == 2 && ADK_SK16_ILV > 0;
+    float4 rbuf[2][RB];
+    float4 abuf[2][8 * KD];
+    // `valid` = false: every load goes out of bounds (returns 0 without touching memory) -- lets the last iterations run the
+    // same straight-line code as the others
+    auto gloadX = [&](float4 (&rb)[RB], bool valid = true) {
+        const bool k_ok = valid && t_tap < a.taps;     // false on the zero-padded K tail
         const unsigned cb = (unsigned)t_cblk * 128u;
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             const unsigned vo = (k_ok && colb[rr] != OOB) ? colb[rr] + rowb[rr] + cb : OOB;
             rb[rr] = buf_load4(rsrc_in, vo, 0);
         }
-        const unsigned sa = s_wbase + (unsigned)s_kc * (8192u * KD);
-#pragma unroll
-        for (int q = 0; q < 8 * KD; ++q) a_nxt[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
     };
-    auto lstore = [&](int buf) {
-        float* Bb = Bs + buf * BN * LDK;
+    auto gloadW = [&](float4 (&af)[8 * KD], bool valid = true) {
+        const unsigned sa = valid ? w_base + (unsigned)w_kc * (8192u * KD) : 0xfff00000u;
 #pragma unroll
-        for (int rr = 0; rr < RB; ++rr) {
+        for (int q = 0; q < 8 * KD; ++q) af[q] = buf_load4(rsrc_w, lane16, sa + q * 1024u);
+    };
+    auto lstore_piece = [&](int buf, const float4 (&rb)[RB], int rr) {
+        float* Bb = Bs + buf * BN * LDK;
+        {
             float4 v = rb[rr];
             if (!(SPLIT && (ADK_SK16_DBG & 2))) {
                 v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
@@ -303,6 +364,10 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
             }
         }
     };
+    auto lstore = [&](int buf, const float4 (&rb)[RB]) {
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) lstore_piece(buf, rb, rr);
+    };
 
     f32x16 acc[NJ];
     f32x16 accx[SPLIT ? NJ : 1];                       // SPLIT: cross-term accumulators (scaled by 2048)
@@ -315,31 +380,116 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
 #pragma unroll
         for (int e = 0; e < 16; ++e) accx[j][e] = 0.f;
 
-    // ---- prologue: first chunk into LDS buffer 0 ----
+    // ---- prologue: first chunk into LDS buffer 0 / register set 0 ----
     int tile = (int)(u0 / sk.nchunks);
     int kc = (int)(u0 - (long long)tile * sk.nchunks);
     int seg_start_kc = kc;                             // first chunk of the current segment
+    const int n_units = (int)(u1 - u0);
     stage_tile(tile, kc);
-    gload();
-    lstore(0);
-    float4 a_cur[8 * KD];
-#pragma unroll
-    for (int q = 0; q < 8 * KD; ++q) a_cur[q] = a_nxt[q];
+    w_set(tile, kc);
     int cur_g = s_g, cur_mt = s_mt, cur_nt = s_nt;
+    gloadX(rbuf[0]);
+    if constexpr (ILV) {
+        // chunk 0's weights and chunk 1's activations in exactly the order (and registers) an odd iteration issues them, so that
+        // the compiler's s_waitcnt bookkeeping at the loop head is the same from here as from the back edge (it merges the two
+        // conservatively: with another order the first even iteration of every pair drained all loads)
+        constexpr int RPS = RB / 4;
+        const bool v1 = n_units > 1;
+        if (v1) stage_advance();
+        const unsigned sa = w_base + (unsigned)w_kc * 8192u;
+        const bool k_ok = v1 && t_tap < a.taps;
+        const unsigned cb = (unsigned)t_cblk * 128u;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            abuf[0][2 * st] = buf_load4(rsrc_w, lane16, sa + (2 * st) * 1024u);
+            abuf[0][2 * st + 1] = buf_load4(rsrc_w, lane16, sa + (2 * st + 1) * 1024u);
+#pragma unroll
+            for (int i = 0; i < RPS; ++i) {
+                const int rr = st * RPS + i;
+                const unsigned vo = (k_ok && colb[rr] != OOB) ? colb[rr] + rowb[rr] + cb : OOB;
+                rbuf[1][rr] = buf_load4(rsrc_in, vo, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        gloadW(abuf[0]);
+        if (XPD == 2 && n_units > 1) { stage_advance(); gloadX(rbuf[1]); }     // chunk 1's activations: consumed at the bottom of iteration 0
+    }
+    lstore(0, rbuf[0]);
     __syncthreads();
 
-    int cur = 0;
-    const int n_units = (int)(u1 - u0);
-    for (int it = 0; it < n_units; ++it) {
-        // -- issue the next chunk's global loads (possibly of the next tile) --
+#if ADK_SK16_DBG & 16
+    __shared__ unsigned long long trace_lds[64 * 8];
+    const bool trace_on = (r == sk.G / 2) && wave == 0;
+    if (trace_on) for (int i = lane; i < 64 * 8; i += 64) trace_lds[i] = 0ull;
+#endif
+    auto iteration = [&](auto parity, int it) {
+        constexpr int P = decltype(parity)::value;
+        constexpr int cur = P;
+        SK_STAMP(0);
+        // -- issue the loads of the coming chunks (possibly of the next tile) --
         const bool has_next = (it + 1 < n_units);
-        if (has_next) {
-            stage_advance();
-            gload();
+        if constexpr (XPD == 2) {
+            // address updates first (they may branch), then ONE straight-line block of loads, MFMAs and conversion that the
+            // scheduler is told to interleave (below): measured with s_memtime stamps (profiles/r2_sk16_timeline.md), the
+            // round-1 order -- all loads, all MFMAs, all conversions, barrier -- ran as three serial phases of ~1000 / 600 /
+            // 1000 cycles in which the four waves of a workgroup, in lockstep behind the barrier, queue up at the same unit
+            const bool has_next2 = (it + 2 < n_units);
+            if (has_next) w_advance();
+            if (has_next2) stage_advance();
+            if (!ILV) { gloadW(abuf[P ^ 1], has_next); gloadX(rbuf[P], has_next2); }
+        } else {
+            if (has_next) { w_advance(); gloadW(abuf[P ^ 1]); stage_advance(); gloadX(rbuf[P ^ 1]); }
         }
+        const float4 (&a_cur)[8 * KD] = abuf[P];
+        if (!ILV) SK_STAMP(1);
         // -- MFMAs on the current chunk --
         const float* Bb = Bs + cur * BN * LDK + (wn * NJ * 32 + l31) * LDK + 4 * lh;
-        if constexpr (SPLIT) {
+        if constexpr (ILV) {
+            // One straight-line block, order pinned by sched_barrier(0): per 16-k step -- B fragments, the two MFMAs that start
+            // the accumulator chains, a quarter of the conversion of the NEXT chunk's activations into the other LDS buffer
+            // (VALU work that runs under those MFMAs), the third MFMA, then a quarter of this iteration's loads (weights of the
+            // next chunk, activations of the one after).  The four waves of a workgroup thus reach the vector-memory unit, the
+            // matrix cores and the VALU at different times instead of queueing up at each in turn.
+            static_assert(RB % 4 == 0 && KD == 1, "interleaved variant: 4 k-steps, RB / 4 staging pieces each");
+            constexpr int RPS = RB / 4;
+            const bool has_next2 = (it + 2 < n_units);
+            const unsigned char* Bh = reinterpret_cast<const unsigned char*>(Bb);
+            const unsigned sa = has_next ? w_base + (unsigned)w_kc * 8192u : 0xfff00000u;
+            const bool k_ok = has_next2 && t_tap < a.taps;
+            const unsigned cb = (unsigned)t_cblk * 128u;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                union { float4 f; f16x8s h; } ah, al;
+                ah.f = a_cur[2 * st]; al.f = a_cur[2 * st + 1];
+                f16x8s bh[NJ], bl[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st);
+                    bl[j] = *reinterpret_cast<const f16x8s*>(Bh + j * 32 * LDK * 4 + 32 * st + 2 * KCC);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bl[j], accx[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RPS; ++i) lstore_piece(cur ^ 1, rbuf[P ^ 1], st * RPS + i);   // (zeros after the last chunk: never read)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bh[j], accx[j], 0, 0, 0);
+                abuf[P ^ 1][2 * st] = buf_load4(rsrc_w, lane16, sa + (2 * st) * 1024u);
+                abuf[P ^ 1][2 * st + 1] = buf_load4(rsrc_w, lane16, sa + (2 * st + 1) * 1024u);
+#pragma unroll
+                for (int i = 0; i < RPS; ++i) {
+                    const int rr = st * RPS + i;
+                    const unsigned vo = (k_ok && colb[rr] != OOB) ? colb[rr] + rowb[rr] + cb : OOB;
+                    rbuf[P][rr] = buf_load4(rsrc_in, vo, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (SPLIT) {
             const unsigned char* Bh = reinterpret_cast<const unsigned char*>(Bb);     // + 4*lh floats = 16*lh bytes: this lane's 8 halfs
 #pragma unroll
             for (int st = 0; st < 4 * KD; ++st) {
@@ -357,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                 for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.h, bl[j], accx[j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.h, bh[j], accx[j], 0, 0, 0);
+                if (st == 0 && !ILV) SK_STAMP(2);
             }
         } else {
             float4 bv[2][NJ];
@@ -379,8 +530,14 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                 for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[q & 1][j].w, acc[j], 0, 0, 0);
             }
         }
+        if (!ILV) SK_STAMP(3);
         // -- stage the next chunk --
-        if (has_next) lstore(cur ^ 1);
+        if constexpr (XPD == 2) {
+            if (!ILV) lstore(cur ^ 1, rbuf[P ^ 1]);     // (zeros after the last chunk: nobody reads that buffer again)
+        } else {
+            if (has_next) lstore(cur ^ 1, rbuf[P ^ 1]);
+        }
+        SK_STAMP(4);
         // -- end of this tile's segment? --
         if (kc == sk.nchunks - 1 || !has_next) {
             const int ml0 = (cur_mt * WGM + wm) * 32;
@@ -397,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                 // Head of this range: the tile started in an earlier range, whose workgroup owns it.
                 // Publish the raw partial accumulators: write-through (sc1) stores, drain, one flag.
                 const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(sk.ws, 0, sk.ws_bytes, 0x00020000);
-                const unsigned wbase = ((unsigned)r * 256u + (unsigned)tid) * (unsigned)(NJ * 64);
+                const unsigned wbase = ((unsigned)r * (unsigned)NT + (unsigned)tid) * (unsigned)(NJ * 64);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -427,12 +584,34 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                                 if (++spins > (1u << 20)) { atomicOr(sk.err, 2); break; }     // never hang the device
                             }
                         }
+#if !ADK_SK_SC1_READ
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                     }
                     __syncthreads();
+#if ADK_SK_SC1_READ
+                    // the partial tiles were stored write-through (sc1); reading them with sc1 loads (served by L2, never by this
+                    // CU's L1) needs no acquire fence (MI355X_MICROARCH.md, inter-workgroup visibility: "16 B sc1 stores AND sc1
+                    // loads"; the fence costs ~1.7 us)
+                    const __amdgpu_buffer_rsrc_t rsrc_rd = __builtin_amdgcn_make_buffer_rsrc(sk.ws, 0, sk.ws_bytes, 0x00020000);
+#endif
                     for (int rr = r + 1; rr < rr_end; ++rr) {
                         if (sk_u0(rr + 1, sk) <= sk_u0(rr, sk)) continue;
-                        const float* wsp = sk.ws + ((size_t)rr * 256 + tid) * (NJ * 16);
+#if ADK_SK_SC1_READ
+                        const unsigned rbase = ((unsigned)rr * (unsigned)NT + (unsigned)tid) * (unsigned)(NJ * 64);
+                        u32x4 pv[NJ * 4];
+#pragma unroll
+                        for (int q = 0; q < NJ * 4; ++q) pv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rd, rbase + (unsigned)(q * 16), 0, 16 /* sc1 */);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4) {
+                                const u32x4 v = pv[j * 4 + e4];
+                                acc[j][4 * e4] += __uint_as_float(v.x); acc[j][4 * e4 + 1] += __uint_as_float(v.y);
+                                acc[j][4 * e4 + 2] += __uint_as_float(v.z); acc[j][4 * e4 + 3] += __uint_as_float(v.w);
+                            }
+#else
+                        const float* wsp = sk.ws + ((size_t)rr * NT + tid) * (NJ * 16);
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -440,6 +619,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
                                 const float4 v = *reinterpret_cast<const float4*>(wsp + j * 16 + 4 * e4);
                                 acc[j][4 * e4] += v.x; acc[j][4 * e4 + 1] += v.y; acc[j][4 * e4 + 2] += v.z; acc[j][4 * e4 + 3] += v.w;
                             }
+#endif
                     }
                 }
                 sk_epilogue<NJ, SPLIT>(a, acc, cur_g, ml0, n0w, lane, sk.err);
@@ -449,14 +629,33 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(ConvArgs a, SkArgs sk) 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
             seg_start_kc = 0;
-            cur_g = s_g; cur_mt = s_mt; cur_nt = s_nt;   // staged tile = the next tile (if any)
+            if (has_next) sk_tile_coords(tile + 1, sk, cur_g, cur_mt, cur_nt);
         }
+        SK_STAMP(5);
         __syncthreads();
-        cur ^= 1;
-#pragma unroll
-        for (int q = 0; q < 8 * KD; ++q) a_cur[q] = a_nxt[q];
+        SK_STAMP(6);
         if (++kc == sk.nchunks) { kc = 0; ++tile; }
+    };
+#if ADK_SK16_DBG & 32
+    const unsigned long long wg_t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wg_t2 = 0;
+#endif
+    for (int it = 0; it < n_units; it += 2) {
+#if ADK_SK16_DBG & 32
+        if (it + 2 >= n_units) wg_t2 = __builtin_amdgcn_s_memrealtime();      // before the last (pair of) iteration(s): the segment-end wait is in there
+#endif
+        iteration(std::integral_constant<int, 0>(), it);
+        if (it + 1 < n_units) iteration(std::integral_constant<int, 1>(), it + 1);
     }
+#if ADK_SK16_DBG & 32
+    if (tid == 0 && r < 512) {
+        g_sk_wg_trace[r * 4] = wg_t0; g_sk_wg_trace[r * 4 + 1] = wg_t1; g_sk_wg_trace[r * 4 + 2] = wg_t2;
+        g_sk_wg_trace[r * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#if ADK_SK16_DBG & 16
+    if (trace_on) for (int i = lane; i < 64 * 8; i += 64) g_sk_trace[i] = trace_lds[i];
+#endif
 }
 
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
@@ -493,8 +692,9 @@ bool conv_mfma_supported(const ConvArgs& a) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct Cfg { int wgm, wgn, nj; const char* name; };
-const Cfg kCfgs[6] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"}, {2, 2, 1, "conv_sk<64x64>"},
-                      {2, 2, 2, "conv_sk<64x128>"}, {1, 4, 1, "conv_sk<32x128>"}, {1, 4, 2, "conv_sk<32x256>"}};
+const Cfg kCfgs[7] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"}, {2, 2, 1, "conv_sk<64x64>"},
+                      {2, 2, 2, "conv_sk<64x128>"}, {1, 4, 1, "conv_sk<32x128>"}, {1, 4, 2, "conv_sk<32x256>"},
+                      {4, 2, 2, "conv_sk<128x128w8>"}};       // 6: 8 waves (512 threads), split variant only
 int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
 int g_fixed_g = 0;         // persistent workgroups per launch when > 0 (ADK_CONV_G / adk_set_conv_workgroups), else 256 * g_occ
@@ -506,7 +706,7 @@ int g_min_units = 2;       // minimum K chunks per workgroup (ADK_CONV_MIN_UNITS
 
 template <int WGM, int WGN, int NJ, bool SPLIT, int KD = 1>
 int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
-    constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN;
+    constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN, NT = 64 * WGM * WGN;
     constexpr int KCC = KC * KD;
     constexpr size_t lds = 2ull * BN * (KCC + 4) * sizeof(float);
     SkArgs sk;
@@ -528,14 +728,15 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     sk.total = tiles * sk.nchunks;
     // persistent workgroups: 256 CUs x occupancy, but never fewer than g_min_units chunks per workgroup
     // (each one pays a fixed prologue/epilogue, and every cut of a tile costs a partial round trip)
-    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, 256LL * g_occ) : (g_fixed_g > 0 ? g_fixed_g : 256LL * g_occ);
+    const long long slots = NT == 256 ? 256LL * g_occ : 256LL;        // resident workgroups: 512-thread workgroups are alone on their CU
+    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, slots) : (g_fixed_g > 0 ? std::min<long long>(g_fixed_g, slots) : slots);
     long long G = cap;
     const long long by_units = (sk.total + g_min_units - 1) / g_min_units;
     if (G > by_units) G = (by_units + 7) / 8 * 8;
     // ... and never more than g_max_split workgroups on one tile: its owner adds the others' partial tiles one after the
     // other, which is what a launch over few tiles (few streams, or the deepest layers) otherwise spends its time on
     if (g_max_split > 0 && G > tiles * g_max_split) G = (tiles * g_max_split + 7) / 8 * 8;
-    sk.split = 0; sk.tpw = 0; sk.tiles = (int)tiles;
+    sk.split = 0; sk.tpw = 0; sk.tiles = (int)tiles; sk.owner_chunks = 0;
     // Tile-aligned ranges (measured, tools/run_r2z.sh at 256 streams: a range that straddles two tiles pays two partial round
     // trips -- 200-tile 1x1 / strided / transposed convs 20.7 -> 10.8 / 13.0 / 13.4 us with one whole tile per workgroup, the
     // grouped K11 256-channel conv 50.8 -> 44.3 us with exact halves).  Short K (<= 8 chunks): whole tiles, as many per
@@ -550,10 +751,18 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
             if (sp < 1) sp = 1;
             while (sp > 1 && (tiles * sp > cap || sk.nchunks / sp < g_min_units)) --sp;
             if (sp > 1 || sk.nchunks < 12) { sk.split = (int)sp; G = tiles * sp; }
+            // two workgroups per tile AND per CU: the owners run on the later-dispatched blocks (see the kernel), which get the
+            // smaller share of a CU -- give them the smaller share of the tile (ADK_CONV_OWNER_SHARE percent, default 45)
+            sk.owner_chunks = sk.nchunks / 2;
+            if (sk.split == 2 && G >= 448) {             // (measured: grouped K11 256-channel conv, G = 480: 41.9 -> 39.5 us; G = 400 loses)
+                static int share = -1;
+                if (share < 0) { const char* e = getenv("ADK_CONV_OWNER_SHARE"); share = (e && atoi(e) >= 10 && atoi(e) <= 90) ? atoi(e) : 45; }
+                sk.owner_chunks = std::max(g_min_units, std::min(sk.nchunks - g_min_units, (sk.nchunks * share + 50) / 100));
+            }
         }
     }
     sk.G = (int)G;
-    const size_t part_bytes = (size_t)sk.G * 256 * NJ * 16 * sizeof(float);
+    const size_t part_bytes = (size_t)sk.G * NT * NJ * 16 * sizeof(float);
     if (!ws.ptr || part_bytes + (size_t)sk.G * sizeof(unsigned) > ws.bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
     sk.ws = ws.ptr;
     sk.ws_bytes = (unsigned)part_bytes;
@@ -573,11 +782,11 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     }
     const unsigned grid = (unsigned)((sk.G + 7) / 8 * 8);
     if (a.act_in == ADK_ACT_ELU)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), dim3(grid), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), dim3(grid), dim3(NT), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_LEAKY)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), dim3(grid), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_LEAKY, SPLIT, KD>), dim3(grid), dim3(NT), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_NONE)
-        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT, KD>), dim3(grid), dim3(256), lds, s, a, sk);
+        hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_NONE, SPLIT, KD>), dim3(grid), dim3(NT), lds, s, a, sk);
     else
         return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
     ADK_HIP_CHECK(hipGetLastError());
@@ -586,6 +795,19 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
 }  // namespace
 
 void conv_mfma_force_cfg(int cfg) { g_forced_cfg = cfg; }
+
+#if ADK_SK16_DBG & 32
+extern "C" int adk_debug_sk_wg_trace(unsigned long long* out, int n) {   // debug builds only
+    if (n > 512 * 4) n = 512 * 4;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sk_wg_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+#if ADK_SK16_DBG & 16
+extern "C" int adk_debug_sk_trace(unsigned long long* out, int n) {      // debug builds only (tools/kbench looks it up with dlsym)
+    if (n > 64 * 8) n = 64 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sk_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // workspace = partial slots [G][256][NJ<=4][16] floats, then G publish flags
 size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
@@ -628,7 +850,7 @@ int launch_conv_mfma(const ConvArgs& a, hipStream_t s, Workspace& ws) {
 // split-f16 variant: wfrag = adk_pack_weights_split16 layout
 int conv_sk16_pick(const ConvArgs& a) {
     if (g_forced_cfg == -2) { const char* e = getenv("ADK_CONV_CFG"); g_forced_cfg = e ? atoi(e) : -1; }
-    if (g_forced_cfg >= 0 && g_forced_cfg <= 5) return g_forced_cfg;
+    if (g_forced_cfg >= 0 && g_forced_cfg <= 6) return g_forced_cfg;
     // with the matrix-core time cut to 3/16 the weight / activation re-reads weigh more: 128-row tiles (each X chunk
     // staged once per 128 output channels) win when that still leaves >= 256 tiles (measured: grouped 128-channel
     // vocoder stage 47.7 vs 55.2 us; the 100-tile encoder block loses, 34.6 vs 28.2 us)
@@ -657,6 +879,7 @@ int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
         case 2: return launch_cfg<2, 2, 1, true>(a, s, ws);
         case 3: return launch_cfg<2, 2, 2, true>(a, s, ws);
         case 4: return launch_cfg<1, 4, 1, true>(a, s, ws);
+        case 6: return launch_cfg<4, 2, 2, true>(a, s, ws);
         default: return launch_cfg<1, 4, 2, true>(a, s, ws);
     }
 }

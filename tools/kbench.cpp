@@ -8,9 +8,11 @@
 // Build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include tools/kbench.cpp -L audiodec_amd -laudiodec_hip -Wl,-rpath,'$ORIGIN/../../audiodec_amd' -o tools/bin/kbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <random>
@@ -109,6 +111,39 @@ static int cmd_conv(int argc, char** argv) {
     }
     int32_t flags = 0; AK(adk_debug_flags(&flags));
     printf("  flags %d\n", flags);
+    // debug builds of the library (-DADK_SK16_DBG=16) record an s_memtime timeline of one workgroup of the last launch
+    typedef int (*trace_fn)(unsigned long long*, int);
+    if (trace_fn tf = (trace_fn)dlsym(RTLD_DEFAULT, "adk_debug_sk_trace")) {
+        std::vector<unsigned long long> tr(64 * 8);
+        if (tf(tr.data(), 64 * 8) == 0) {
+            printf("  iteration timeline of one workgroup, wave 0 (s_memtime ticks between stamps: loads issued | first MFMA step | all MFMAs issued | converted + staged | segment end | barrier)\n");
+            double sum[7] = {0}; int cnt = 0;
+            for (int it = 0; it < 64 && tr[it * 8] != 0; ++it) {
+                const unsigned long long* t = &tr[it * 8];
+                if (!t[6]) break;
+                const double d[6] = {double(t[1] - t[0]), double(t[2] - t[1]), double(t[3] - t[2]), double(t[4] - t[3]), double(t[5] - t[4]), double(t[6] - t[5])};
+                const double gap = it > 0 && tr[(it - 1) * 8 + 6] ? double(t[0] - tr[(it - 1) * 8 + 6]) : 0.0;
+                if (it < 24) printf("   it %2d: %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f   (+%.0f to the next top)  total %6.0f\n", it, d[0], d[1], d[2], d[3], d[4], d[5], gap, double(t[6] - t[0]));
+                if (it >= 1) { for (int k = 0; k < 6; ++k) sum[k] += d[k]; sum[6] += gap; ++cnt; }
+            }
+            if (cnt) printf("   mean over %d iterations: %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f  gap %.0f\n", cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt);
+        }
+    }
+    if (trace_fn wf = (trace_fn)dlsym(RTLD_DEFAULT, "adk_debug_sk_wg_trace")) {
+        std::vector<unsigned long long> tr(512 * 4);
+        if (wf(tr.data(), 512 * 4) == 0) {
+            unsigned long long t0 = ~0ull, t3 = 0; int n = 0;
+            for (int r = 0; r < 512; ++r) if (tr[r * 4]) { t0 = std::min(t0, tr[r * 4]); t3 = std::max(t3, tr[r * 4 + 3]); ++n; }
+            printf("  per-workgroup wall clock of the last launch (10 ns ticks since the first workgroup started; %d workgroups, span %llu):\n", n, t3 - t0);
+            printf("   range: start  loop-entry  before-last-iterations  end\n");
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int r = 0; r < 512; ++r) if (tr[r * 4]) {
+                if (r % 16 == 0 || tr[r * 4 + 3] == t3) printf("   %3d: %5llu %5llu %5llu %5llu%s\n", r, tr[r * 4] - t0, tr[r * 4 + 1] - t0, tr[r * 4 + 2] - t0, tr[r * 4 + 3] - t0, tr[r * 4 + 3] == t3 ? "  <- last" : "");
+                s0 += tr[r * 4] - t0; s1 += tr[r * 4 + 1] - t0; s2 += tr[r * 4 + 2] - t0; s3 += tr[r * 4 + 3] - t0;
+            }
+            printf("   mean: %5.0f %5.0f %5.0f %5.0f\n", s0 / n, s1 / n, s2 / n, s3 / n);
+        }
+    }
     return 0;
 }
 
