@@ -141,6 +141,40 @@ def test_conv_kernels_agree_with_oracle(gpu, cin, cout, k, s, d, gr, act, B, L):
             assert float((y - ref).abs().max()) < 2e-5, (m.impl, step)
 
 
+@pytest.mark.parametrize("cin,cout,k,s,d,gr,act,B,L,what", [
+    (768, 768, 11, 1, 5, 3, "LeakyReLU", 256, 5, "240 tiles x 44 chunks: two workgroups per tile, owners on the late blocks with 45 % of the tile"),
+    (128, 128, 7, 1, 9, 1, "ELU", 256, 25, "200 tiles x 14 chunks: exact halves, 400 workgroups"),
+    (256, 256, 7, 1, 9, 1, "ELU", 64, 5, "20 tiles x 28 chunks: five workgroups per tile"),
+    (128, 192, 3, 1, 1, 1, None, 37, 5, "9 tiles x 6 chunks: three per tile, 27 workgroups (not a multiple of 8)"),
+    (64, 128, 1, 1, 1, 1, None, 300, 100, "938 one-chunk tiles: several whole tiles per workgroup"),
+    (384, 128, 1, 1, 1, 1, None, 256, 25, "200 tiles x 6 chunks: one whole tile per workgroup"),
+    (384, 384, 11, 1, 5, 3, "LeakyReLU", 256, 25, "300 tiles x 22 chunks: balanced split, ranges cut anywhere"),
+    (512, 1280, 2, 1, 1, 1, "LeakyReLU", 256, 1, "80 tiles x 16 chunks: three per tile"),
+    (64, 64, 3, 1, 1, 1, "ELU", 1, 3, "one tile, three chunks: a single workgroup"),
+])
+def test_streamk_schedules_agree_with_direct_kernel(gpu, cin, cout, k, s, d, gr, act, B, L, what):
+    """Every range layout of the stream-K launch (conv_mfma.hip launch_cfg / sk_u0: tile-aligned splits incl. the uneven
+    two-per-tile one, whole tiles, several tiles per workgroup, the balanced split; any workgroup count) for both arithmetics
+    against the scalar direct kernel, over calls that wrap the ring."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(cin + 13 * k + B)
+    w = torch.randn(cout, cin // gr, k, generator=g) / (cin // gr * k) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    mods = {}
+    for impl in (native.IMPL_DIRECT, native.IMPL_MFMA, native.IMPL_SPLIT16_SK):
+        m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
+        m.set_activation(act, 0.1)
+        m.impl = impl
+        mods[impl] = m
+    for step in range(3):
+        x = torch.randn(B, cin, L * s, generator=g).to(gpu)
+        ref = mods[native.IMPL_DIRECT].inference(x)
+        for impl in (native.IMPL_MFMA, native.IMPL_SPLIT16_SK):
+            y = mods[impl].inference(x)
+            assert float((y - ref).abs().max()) < 2e-5, (what, impl, step)
+    assert native.device_flags() == 0
+
+
 def test_split16_weight_packing_kernel_matches_host_packing(gpu):
     import ctypes as ct
     from audiodec_amd import native, program
