@@ -30,9 +30,22 @@ struct ConvArgs {
     int ktot;                       // taps * cin_g
 };
 
+// expm1(x) for x <= 0 (the negative branch of torch.nn.ELU, layers/activation_function.py:18-22 -> torch.nn.ELU).  The library
+// expm1f costs ~30 VALU instructions per element, and the ELU convs convert every activation they stage: measured with
+// s_memtime stamps (profiles/r2_sk16_timeline.md) the conversion was 2900 of the 4700 cycles of an iteration of the encoder's
+// K7 256-channel conv.  Here: |x| < 0.4 -- x + x^2 (1/2 + x/6 + ... + x^5/5040) (truncation < 1.5e-8 relative); else
+// exp2(x log2 e) - 1 on the transcendental unit (result in [-1, -0.33]: no cancellation).  Max relative error against fp64
+// 1.4e-7 (1.2 ulp; numpy restatement in tests/test_cabi.py), NaN propagates, -inf -> -1.
+__device__ __forceinline__ float expm1_neg(float x) {
+    const float q = fmaf(fmaf(fmaf(fmaf(fmaf(1.f / 5040.f, x, 1.f / 720.f), x, 1.f / 120.f), x, 1.f / 24.f), x, 1.f / 6.f), x, 0.5f);
+    const float p = fmaf(x * x, q, x);
+    const float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.0f;
+    return x > -0.4f ? p : e;
+}
+
 __device__ __forceinline__ float act_apply(float x, int act, float slope) {
     // torch.nn.ELU(alpha=1): x > 0 ? x : expm1(x); LeakyReLU: x > 0 ? x : x*slope; Tanh
-    if (act == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (act == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
     if (act == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
     if (act == ADK_ACT_TANH) return tanhf(x);
     return x;

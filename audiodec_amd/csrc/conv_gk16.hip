@@ -62,7 +62,7 @@ struct GkArgs {
 
 template <int ACT>
 __device__ __forceinline__ float gk_act(float x, float slope) {
-    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
     if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
     return x;
 }

@@ -102,7 +102,7 @@ struct SkArgs {
 
 template <int ACT>
 __device__ __forceinline__ float act_in_apply(float x, float slope) {
-    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
     if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
     return x;
 }

@@ -35,7 +35,7 @@ __device__ __forceinline__ float4 rl_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 
 template <int ACT>
 __device__ __forceinline__ float rl_act(float x, float slope) {
-    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
     if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
     return x;
 }

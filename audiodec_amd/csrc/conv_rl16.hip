@@ -45,7 +45,7 @@ constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
 template <int ACT>
 __device__ __forceinline__ float rl16_act(float x, float slope) {
-    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
     if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
     return x;
 }

@@ -30,7 +30,7 @@ constexpr int UP_CIN = 64, UP_KSTEPS = 2 * UP_CIN / 16;          // 2 taps x 64 
 
 template <int ACT>
 __device__ __forceinline__ float up_act(float x, float slope) {
-    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
     if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
     return x;
 }

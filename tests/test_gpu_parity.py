@@ -175,6 +175,25 @@ def test_streamk_schedules_agree_with_direct_kernel(gpu, cin, cout, k, s, d, gr,
     assert native.device_flags() == 0
 
 
+def test_elu_of_the_kernels_against_fp64(gpu):
+    """The kernels' own ELU (expm1_neg, csrc/adk_common.h) through an identity 1x1 conv on the exact-f32 kernels: relative error
+    against torch's fp64 ELU <= 4e-7 over [-20, 2] (the reference applies torch.nn.ELU in fp32: layers/activation_function.py:18-22)."""
+    from audiodec_amd import layers, native
+    C, L = 32, 4096
+    w = torch.eye(C).unsqueeze(-1)
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([-torch.logspace(-7, 1.3, C * L // 2, dtype=torch.float64), torch.rand(C * L // 2, generator=g, dtype=torch.float64) * 3 - 1])
+    x = x[torch.randperm(C * L, generator=g)].float().view(1, C, L)
+    ref = torch.nn.functional.elu(x.double())
+    for impl in (native.IMPL_DIRECT, native.IMPL_MFMA):
+        m = layers.CausalConv1d(C, C, 1, 1, 1, 1, False, device=gpu, batch=1, max_len=L).load(w, None)
+        m.set_activation("ELU", 0.0)
+        m.impl = impl
+        y = m.inference(x).cpu().double()
+        rel = ((y - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+        assert rel < 4e-7, (impl, rel)
+
+
 def test_split16_weight_packing_kernel_matches_host_packing(gpu):
     import ctypes as ct
     from audiodec_amd import native, program
