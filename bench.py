@@ -30,8 +30,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA pe
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_MARKER_N = 7654321                         # --pmc-markers: element count of the marker launches
 PMC_TRAFFIC_FILE = "r2_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench (tools/run_r2k.sh)
-PMC_TRAFFIC_SCRIPT = "tools/run_r2k.sh"
-PMC_TRAFFIC_COMMIT = "82a09df"                 # the commit those passes were taken at
+PMC_TRAFFIC_SCRIPT = "tools/run_r3p.sh"
+PMC_TRAFFIC_COMMIT = "33351fd"                 # the commit those passes were taken at
 
 
 def build_audiodec(root, device, streams, max_frames, sd_bcast=False):
