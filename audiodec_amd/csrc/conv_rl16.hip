@@ -16,10 +16,19 @@
 #include <cstdlib>
 
 #ifndef ADK_RL16_DBG
-#define ADK_RL16_DBG 0      // tuning experiments only: 1 = reuse the first weight fragment, 2 = no epilogue stores, 4 = no MFMA, 8 = no staging loads
+#define ADK_RL16_DBG 0      // tuning experiments only: 1 = reuse the first weight fragment, 2 = no epilogue stores, 4 = no MFMA, 8 = no staging loads, 16 = per-workgroup wall clocks
 #endif
 
 namespace adk {
+
+#if ADK_RL16_DBG & 16
+// per-workgroup wall-clock stamps (s_memrealtime, 100 MHz): entry, rows staged, MFMAs done, exit (tools/kbench prints them)
+__device__ unsigned long long g_rl_wg_trace[2048 * 4];
+extern "C" int adk_debug_rl_wg_trace(unsigned long long* out, int n) {
+    if (n > 2048 * 4) n = 2048 * 4;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rl_wg_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -83,6 +92,10 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
+#if ADK_RL16_DBG & 16
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr1 = 0, tr2 = 0;
+#endif
 
     const int g = blockIdx.x % a.groups;
     const int rest = blockIdx.x / a.groups;
@@ -178,6 +191,9 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
         }
     }
     __syncthreads();
+#if ADK_RL16_DBG & 16
+    tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     f32x16 m0, m1, c0, c1;                              // main / cross-term accumulators of the two n-tiles
     int mt = 0, nt0 = 0;
@@ -220,6 +236,11 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
             }
         }
+#if ADK_RL16_DBG & 16
+        __builtin_amdgcn_sched_barrier(0);
+        tr2 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if constexpr (FUSE) break;                      // at most one item per wave; phase 2 below consumes the accumulators
         // ---- epilogue: acc0 + acc1/2048, bias, residual, output activation, store.  An operand beyond the f16 range was
         // split into inf parts, so every output it feeds is non-finite: checked here, once per output ----
@@ -375,6 +396,12 @@ __global__ __launch_bounds__(64 * NW, ((PF > 4 || PF >= TAPS * C / 16) ? 2 : 3))
         }
         if (bad) atomicOr(rl.err, 8);
     }
+#if ADK_RL16_DBG & 16
+    if (wave == 0 && lane == 0 && blockIdx.x < 2048) {
+        unsigned long long* t = g_rl_wg_trace + (size_t)blockIdx.x * 4;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // w [groups*cout_g][ktot] row-major (k = tap*cin_g + ci) -> [g][m-tile 32][16-k chunk][hi | lo][lane 64][8 halfs],

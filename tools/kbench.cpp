@@ -144,6 +144,23 @@ static int cmd_conv(int argc, char** argv) {
             printf("   mean: %5.0f %5.0f %5.0f %5.0f\n", s0 / n, s1 / n, s2 / n, s3 / n);
         }
     }
+    if (trace_fn wf = (trace_fn)dlsym(RTLD_DEFAULT, "adk_debug_rl_wg_trace")) {
+        std::vector<unsigned long long> tr(2048 * 4);
+        if (wf(tr.data(), 2048 * 4) == 0) {
+            unsigned long long t0 = ~0ull, t3 = 0; int n = 0;
+            for (int r = 0; r < 2048; ++r) if (tr[r * 4]) { t0 = std::min(t0, tr[r * 4]); t3 = std::max(t3, tr[r * 4 + 3]); ++n; }
+            printf("  rows kernel, per-workgroup wall clock of the last launch (10 ns ticks since the first workgroup started; %d workgroups, span %llu):\n", n, t3 - t0);
+            printf("   block: start  rows-staged  wave-0-MFMAs-done  end    | phase lengths\n");
+            double s[4] = {0, 0, 0, 0}, ph[3] = {0, 0, 0};
+            for (int r = 0; r < 2048; ++r) if (tr[r * 4]) {
+                const unsigned long long* t = &tr[r * 4];
+                if (r % 96 == 0 || t[3] == t3) printf("   %4d: %5llu %5llu %5llu %5llu | %4llu %4llu %4llu%s\n", r, t[0] - t0, t[1] - t0, t[2] - t0, t[3] - t0, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[3] == t3 ? "  <- last" : "");
+                for (int k = 0; k < 4; ++k) s[k] += double(t[k] - t0);
+                ph[0] += double(t[1] - t[0]); ph[1] += double(t[2] - t[1]); ph[2] += double(t[3] - t[2]);
+            }
+            printf("   mean: %5.0f %5.0f %5.0f %5.0f | %4.0f %4.0f %4.0f\n", s[0] / n, s[1] / n, s[2] / n, s[3] / n, ph[0] / n, ph[1] / n, ph[2] / n);
+        }
+    }
     return 0;
 }
 
