@@ -108,5 +108,7 @@ bool conv_mfma_supported(const ConvArgs& a);
 int conv_mfma_pick(const ConvArgs& a);
 const char* conv_mfma_cfg_name(int pick);
 void conv_mfma_force_cfg(int cfg);
+int streamk_plan(long long tiles, int nchunks, int cap, int out[4]);
+long long streamk_range_start(long long tiles, int nchunks, const int plan[4], int r);
 
 }  // namespace adk

@@ -107,19 +107,22 @@ __device__ __forceinline__ float act_in_apply(float x, float slope) {
     return x;
 }
 
-// first work unit of range r (r = G: one past the last)
+// first work unit of range r (r = G: one past the last) -- shared by the kernels and adk_streamk_range_start
+__host__ __device__ __forceinline__ long long sk_range_start(int r, int G, int split, int tpw, int tiles, int nchunks, int owner_chunks, long long total) {
+    if (split > 0) {
+        const int t = r / split, p = r - t * split;
+        if (split == 2) return (long long)t * nchunks + (p ? owner_chunks : 0);
+        return (long long)t * nchunks + (p * nchunks) / split;
+    }
+    if (tpw > 0) {
+        long long t = (long long)r * tpw;
+        if (t > tiles) t = tiles;
+        return t * nchunks;
+    }
+    return (long long)r * total / G;
+}
 __device__ __forceinline__ long long sk_u0(int r, const SkArgs& sk) {
-    if (sk.split > 0) {
-        const int t = r / sk.split, p = r - t * sk.split;
-        if (sk.split == 2) return (long long)t * sk.nchunks + (p ? sk.owner_chunks : 0);
-        return (long long)t * sk.nchunks + (p * sk.nchunks) / sk.split;
-    }
-    if (sk.tpw > 0) {
-        long long t = (long long)r * sk.tpw;
-        if (t > sk.tiles) t = sk.tiles;
-        return t * sk.nchunks;
-    }
-    return (long long)r * sk.total / sk.G;
+    return sk_range_start(r, sk.G, sk.split, sk.tpw, sk.tiles, sk.nchunks, sk.owner_chunks, sk.total);
 }
 
 // Epilogue for one wave's 32 x (32*NJ) accumulator block: bias, residual, output activation, store.
@@ -704,32 +707,13 @@ int g_max_split = 5;       // most workgroups sharing one tile (ADK_CONV_MAX_SPL
                            // K10 strided 24.1 -> 19.3; at 1 stream the grouped K11 256-channel conv 28.3 -> 18.9, projector 19.9 -> 13.9
 int g_min_units = 2;       // minimum K chunks per workgroup (ADK_CONV_MIN_UNITS; 2 measured best at 256 streams)
 
-template <int WGM, int WGN, int NJ, bool SPLIT, int KD = 1>
-int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
-    constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN, NT = 64 * WGM * WGN;
-    constexpr int KCC = KC * KD;
-    constexpr size_t lds = 2ull * BN * (KCC + 4) * sizeof(float);
-    SkArgs sk;
-    sk.m_tiles = (a.cout_g + BM - 1) / BM;
-    sk.n_tiles = (a.n_total + BN - 1) / BN;
-    sk.nchunks = (a.ktot + KCC - 1) / KCC;
-    sk.cpt = a.cin_g / 32;
-    sk.kgroups = (a.ktot + KC - 1) / KC * (KC / 8);   // packing stride: K padded to 64 whatever the chunk depth
-    sk.mt32_per_g = (a.cout_g + 31) / 32;
-    sk.inv_t_out = 1.0f / (float)a.t_out;
-    {
-        const unsigned long long inb = (unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull;
-        const unsigned long long wb = (unsigned long long)a.groups * sk.mt32_per_g * sk.kgroups * 1024ull;
-        if (inb >= 0x80000000ull || wb >= 0xfff00000ull || a.n_total >= (1 << 24))
-            return fail(ADK_ERR_SHAPE, "conv: problem too large for the 32-bit buffer addressing of the MFMA kernel");
-        sk.in_bytes = (unsigned)inb; sk.w_bytes = (unsigned)wb;
-    }
-    const long long tiles = (long long)sk.m_tiles * sk.n_tiles * a.groups;
+// How many persistent workgroups a launch over `tiles` tiles of sk.nchunks chunks takes (at most `cap`) and where their ranges
+// are cut: fills sk.split / tpw / tiles / owner_chunks / total, returns G.  Pure host logic (adk_streamk_plan exposes it to the
+// CPU tests).
+long long sk_plan(long long tiles, long long cap, SkArgs& sk) {
     sk.total = tiles * sk.nchunks;
     // persistent workgroups: 256 CUs x occupancy, but never fewer than g_min_units chunks per workgroup
     // (each one pays a fixed prologue/epilogue, and every cut of a tile costs a partial round trip)
-    const long long slots = NT == 256 ? 256LL * g_occ : 256LL;        // resident workgroups: 512-thread workgroups are alone on their CU
-    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, slots) : (g_fixed_g > 0 ? std::min<long long>(g_fixed_g, slots) : slots);
     long long G = cap;
     const long long by_units = (sk.total + g_min_units - 1) / g_min_units;
     if (G > by_units) G = (by_units + 7) / 8 * 8;
@@ -761,6 +745,34 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
             }
         }
     }
+    return G;
+}
+
+template <int WGM, int WGN, int NJ, bool SPLIT, int KD = 1>
+int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
+    constexpr int BM = 32 * WGM, BN = 32 * NJ * WGN, NT = 64 * WGM * WGN;
+    constexpr int KCC = KC * KD;
+    constexpr size_t lds = 2ull * BN * (KCC + 4) * sizeof(float);
+    SkArgs sk;
+    sk.m_tiles = (a.cout_g + BM - 1) / BM;
+    sk.n_tiles = (a.n_total + BN - 1) / BN;
+    sk.nchunks = (a.ktot + KCC - 1) / KCC;
+    sk.cpt = a.cin_g / 32;
+    sk.kgroups = (a.ktot + KC - 1) / KC * (KC / 8);   // packing stride: K padded to 64 whatever the chunk depth
+    sk.mt32_per_g = (a.cout_g + 31) / 32;
+    sk.inv_t_out = 1.0f / (float)a.t_out;
+    {
+        const unsigned long long inb = (unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull;
+        const unsigned long long wb = (unsigned long long)a.groups * sk.mt32_per_g * sk.kgroups * 1024ull;
+        if (inb >= 0x80000000ull || wb >= 0xfff00000ull || a.n_total >= (1 << 24))
+            return fail(ADK_ERR_SHAPE, "conv: problem too large for the 32-bit buffer addressing of the MFMA kernel");
+        sk.in_bytes = (unsigned)inb; sk.w_bytes = (unsigned)wb;
+    }
+    const long long tiles = (long long)sk.m_tiles * sk.n_tiles * a.groups;
+    sk.total = tiles * sk.nchunks;
+    const long long slots = NT == 256 ? 256LL * g_occ : 256LL;        // resident workgroups: 512-thread workgroups are alone on their CU
+    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, slots) : (g_fixed_g > 0 ? std::min<long long>(g_fixed_g, slots) : slots);
+    const long long G = sk_plan(tiles, cap, sk);
     sk.G = (int)G;
     const size_t part_bytes = (size_t)sk.G * NT * NJ * 16 * sizeof(float);
     if (!ws.ptr || part_bytes + (size_t)sk.G * sizeof(unsigned) > ws.bytes) return fail(ADK_ERR_STATE, "conv: stream-K workspace missing or too small");
@@ -795,6 +807,19 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
 }  // namespace
 
 void conv_mfma_force_cfg(int cfg) { g_forced_cfg = cfg; }
+
+int streamk_plan(long long tiles, int nchunks, int cap, int out[4]) {
+    (void)conv_mfma_workspace_bytes(nullptr);                      // reads the env knobs
+    SkArgs sk{};
+    sk.nchunks = nchunks;
+    const long long slots = 256LL * g_occ;
+    const long long G = sk_plan(tiles, cap > 0 ? std::min<long long>(cap, slots) : slots, sk);
+    out[0] = (int)G; out[1] = sk.split; out[2] = sk.tpw; out[3] = sk.owner_chunks;
+    return ADK_OK;
+}
+long long streamk_range_start(long long tiles, int nchunks, const int plan[4], int r) {
+    return sk_range_start(r, plan[0], plan[1], plan[2], (int)tiles, nchunks, plan[3], tiles * nchunks);
+}
 
 #if ADK_SK16_DBG & 32
 extern "C" int adk_debug_sk_wg_trace(unsigned long long* out, int n) {   // debug builds only

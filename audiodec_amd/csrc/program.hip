@@ -156,6 +156,20 @@ extern "C" const char* adk_last_error(void) { return g_err.c_str(); }
 extern "C" int adk_abi_version(void) { return ADK_ABI_VERSION; }
 extern "C" int adk_set_conv_cfg(int32_t cfg) { conv_mfma_force_cfg(cfg); return ADK_OK; }
 
+extern "C" int adk_streamk_plan(int64_t tiles, int32_t chunks, int32_t cap, int32_t* plan) {
+    if (!plan || tiles < 1 || tiles >= (1ll << 31) / 64 || chunks < 1 || chunks > (1 << 20) || cap < 0) return fail(ADK_ERR_ARG, "adk_streamk_plan: bad argument");
+    int out[4];
+    const int rc = streamk_plan(tiles, chunks, cap, out);
+    for (int i = 0; i < 4; ++i) plan[i] = out[i];
+    return rc;
+}
+
+extern "C" int64_t adk_streamk_range_start(int64_t tiles, int32_t chunks, const int32_t* plan, int32_t r) {
+    if (!plan || tiles < 1 || chunks < 1 || plan[0] < 1 || r < 0 || r > plan[0]) return -1;
+    const int p[4] = {plan[0], plan[1], plan[2], plan[3]};
+    return streamk_range_start(tiles, chunks, p, r);
+}
+
 extern "C" int adk_causal_conv(const adk_conv_desc* d, adk_ring_view in, adk_ring_view out, adk_ring_view res,
                                int32_t batch, int32_t t_out, int32_t impl, void* stream) {
     if (!d) return fail(ADK_ERR_ARG, "adk_causal_conv: null descriptor");

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -51,6 +51,8 @@ SYMBOLS = {
     "adk_abi_version": (C.c_int, []),
     "adk_debug_flags": (C.c_int, [C.POINTER(_i32)]),
     "adk_set_conv_cfg": (C.c_int, [_i32]),
+    "adk_streamk_plan": (C.c_int, [C.c_int64, _i32, _i32, C.POINTER(C.c_int32)]),
+    "adk_streamk_range_start": (C.c_int64, [C.c_int64, _i32, C.POINTER(C.c_int32), _i32]),
     "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
     "adk_causal_conv_describe": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, C.c_char_p, _i32]),
     "adk_causal_conv_time": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _i32, _vp, C.POINTER(C.c_float)]),

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 7
+#define ADK_ABI_VERSION 8
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -70,8 +70,16 @@ int adk_abi_version(void);
  * has launched on; reading synchronises those devices and clears the words.  The Python facade turns a set bit
  * into an exception at its synchronisation points (audiodec_amd/native.py: raise_on_device_flags) */
 int adk_debug_flags(int32_t* out);
-/* tuning hook: force the MFMA conv tile config (0..5), -1 = heuristic (also env ADK_CONV_CFG) */
+/* tuning hook: force the MFMA conv tile config (0..6), -1 = heuristic (also env ADK_CONV_CFG) */
 int adk_set_conv_cfg(int32_t cfg);
+/* Introspection of the stream-K launch schedule (pure host logic, no device needed; used by the CPU tests): a matrix-core conv
+ * launch over `tiles` output tiles of `chunks` 64-deep K chunks each, allowed at most `cap` persistent workgroups (0: the library
+ * default), runs plan[0] workgroups ("ranges").  plan[1] > 0: every tile is cut into plan[1] ranges (plan[1] == 2: the first takes
+ * plan[3] chunks); plan[2] > 0: every range takes plan[2] whole tiles; both 0: tiles * chunks / plan[0] work units each, wherever
+ * that cuts.  adk_streamk_range_start gives the first work unit (tile * chunks + chunk) of range r, r = plan[0]: one past the last;
+ * -1 on a bad argument. */
+int adk_streamk_plan(int64_t tiles, int32_t chunks, int32_t cap, int32_t* plan /* [4] */);
+int64_t adk_streamk_range_start(int64_t tiles, int32_t chunks, const int32_t* plan, int32_t r);
 
 /* A view of one ring for one call. */
 typedef struct {

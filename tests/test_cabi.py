@@ -104,3 +104,40 @@ def test_expm1_neg_formula_error_bound():
     r = np.where(x > f(-0.4), p, e)
     ref = np.expm1(x.astype(np.float64))
     assert np.max(np.abs(r - ref) / np.abs(ref)) < 2.5e-7
+
+
+def test_streamk_plan_covers_every_work_unit_once(lib):
+    """adk_streamk_plan / adk_streamk_range_start (the host logic of conv_mfma.hip launch_cfg + sk_u0, shared with the kernels): for
+    random (tiles, chunks, cap) the ranges start at 0, end at tiles * chunks, never go backwards, respect the cap; a tile-aligned
+    plan never lets a range straddle two tiles (split) or cut a tile (whole tiles), keeps at most 5 ranges on a tile and gives every
+    part of a split tile at least 2 chunks; the layers of the benched pipeline get the plans DESIGN.md describes."""
+    import ctypes as C
+    import random
+    rnd = random.Random(7)
+    cases = [(240, 44, 0), (240, 44, 256), (200, 6, 0), (400, 4, 256), (300, 22, 0), (80, 28, 0), (32, 40, 0), (4, 24, 0), (1, 3, 0), (938, 1, 0)]
+    cases += [(rnd.randint(1, 3000), rnd.randint(1, 60), rnd.choice([0, 0, 8, 64, 256, 384, 512])) for _ in range(400)]
+    plan = (C.c_int32 * 4)()
+    for tiles, chunks, cap in cases:
+        assert lib.adk_streamk_plan(tiles, chunks, cap, plan) == 0
+        G, split, tpw, owner = plan[0], plan[1], plan[2], plan[3]
+        limit = min(cap, 512) if cap else 512
+        assert 1 <= G <= max(limit, 8), (tiles, chunks, cap, list(plan))
+        starts = [lib.adk_streamk_range_start(tiles, chunks, plan, r) for r in range(G + 1)]
+        assert starts[0] == 0 and starts[-1] == tiles * chunks, (tiles, chunks, cap, list(plan))
+        assert all(b >= a for a, b in zip(starts, starts[1:]))
+        assert not (split and tpw)
+        if split:
+            assert G == tiles * split and split <= 5
+            for r in range(G):
+                a, b = starts[r], starts[r + 1]
+                assert a // chunks == r // split and (b - 1) // chunks == r // split, "a range of a split plan stays inside its tile"
+                assert b - a >= (2 if split > 1 else 1)
+            if split == 2:
+                assert starts[1] - starts[0] == owner and 2 <= owner <= chunks - 2
+        if tpw:
+            assert all(a % chunks == 0 for a in starts) and G == -(-tiles // tpw)
+    # the benched layers (256 streams, 64x64 tiles): grouped K11 256-ch -> exact halves with the owner share; 1x1 3C->C -> whole tiles
+    assert lib.adk_streamk_plan(240, 44, 0, plan) == 0 and list(plan) == [480, 2, 0, 20]
+    assert lib.adk_streamk_plan(200, 6, 0, plan) == 0 and list(plan)[:3] == [200, 1, 0]
+    assert lib.adk_streamk_plan(300, 22, 0, plan) == 0 and list(plan)[:3] == [512, 0, 0]
+    assert lib.adk_streamk_plan(0, 4, 0, plan) != 0 and lib.adk_streamk_range_start(10, 4, plan, 10 ** 6) == -1
