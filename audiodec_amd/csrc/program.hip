@@ -75,7 +75,7 @@ static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling stre
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP ||
-           impl == ADK_IMPL_SPLIT16_GK || impl == ADK_IMPL_SPLIT16_BK;
+           impl == ADK_IMPL_SPLIT16_GK || impl == ADK_IMPL_SPLIT16_BK || impl == ADK_IMPL_SPLIT16_PIPE;
 }
 static void read_env() {
     if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
@@ -96,10 +96,14 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
             return fail(ADK_ERR_SHAPE, "conv: the up-sampling streamer takes 2-tap transposed convs with 64 input channels and <= 96 GEMM rows");
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a)))
             return launch_conv_up16(a, s);
+        if (impl == ADK_IMPL_SPLIT16_PIPE) {
+            if (!conv_rp16_pick(a, true)) return fail(ADK_ERR_SHAPE, "conv: the pipelined rows kernel takes the 11-tap layers of the rows-in-LDS kernel");
+            return launch_conv_rp16(a, s);
+        }
         if (impl == ADK_IMPL_SPLIT16_ROWS && !conv_rl16_supported(a))
             return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
         if (impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a)))
-            return launch_conv_rl16(a, s);
+            return (impl == ADK_IMPL_SPLIT16 && conv_rp16_pick(a, false)) ? launch_conv_rp16(a, s) : launch_conv_rl16(a, s);
         if (!ok) return fail(ADK_ERR_SHAPE, "conv: split-f16 kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
@@ -132,6 +136,7 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
     if (is_split16(impl)) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
+        if (impl == ADK_IMPL_SPLIT16_PIPE || (rows && impl == ADK_IMPL_SPLIT16 && conv_rp16_pick(a, false))) return a.cin_g == 32 ? "conv_rp16<32>" : "conv_rp16<64>";
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
         if ((impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_BK) && conv_mfma_supported(a) && conv_bk16_pick(a, impl == ADK_IMPL_SPLIT16_BK))
             return "conv_bk16<128x128>";

@@ -13,7 +13,7 @@ ABI_VERSION = 8
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS, IMPL_SPLIT16, IMPL_SPLIT16_ROWS, IMPL_SPLIT16_SK, IMPL_SPLIT16_UP, IMPL_SPLIT16_GK, IMPL_SPLIT16_BK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS, IMPL_SPLIT16, IMPL_SPLIT16_ROWS, IMPL_SPLIT16_SK, IMPL_SPLIT16_UP, IMPL_SPLIT16_GK, IMPL_SPLIT16_BK, IMPL_SPLIT16_PIPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 OP_CONV, OP_RING_WRITE, OP_MEAN, OP_HIST_REPLICATE = 0, 1, 2, 3
 
 

@@ -326,3 +326,28 @@ def test_fused_residual_units_are_bit_identical(gpu, ckpt_root, model, B, max_fr
             assert torch.equal(yf, yu), i
     from audiodec_amd import native
     assert native.device_flags() == 0
+
+
+@pytest.mark.parametrize("C_,gr,d,B,L,res", [(64, 3, 5, 300, 100, False), (32, 3, 1, 280, 300, True), (64, 1, 3, 7, 333, False), (32, 3, 5, 2, 40, False)])
+def test_pipelined_rows_kernel_is_bit_identical_to_the_rows_kernel(gpu, C_, gr, d, B, L, res):
+    """conv_rp16 (csrc/conv_rp16.hip, opt-in: ADK_IMPL_SPLIT16_PIPE / ADK_CONV_RP16=1) keeps the per-output MFMA order of conv_rl16,
+    so every output bit must agree: several items per persistent workgroup (> 256 items), ragged last time tile, one and two
+    n-tiles per wave item, with and without the residual input, over calls that wrap the ring."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(C_ + B)
+    cin = cout = C_ * gr
+    w = torch.randn(cout, C_, 11, generator=g) / (C_ * 11) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    mods = []
+    for impl in (native.IMPL_SPLIT16_ROWS, native.IMPL_SPLIT16_PIPE):
+        m = layers.CausalConv1d(cin, cout, 11, 1, d, gr, True, device=gpu, batch=B, max_len=L).load(w, bias)
+        m.set_activation("LeakyReLU", 0.1)
+        m.impl = impl
+        mods.append(m)
+    for step in range(3):
+        x = torch.randn(B, cin, L, generator=g).to(gpu)
+        r = torch.randn(B, cout, L, generator=g).to(gpu) if res else None
+        ya, yb = (m.inference(x, residual=r) if res else m.inference(x) for m in mods)
+        assert torch.equal(ya, yb), step
+    assert mods[1].last_kernel.startswith("conv_rp16"), mods[1].last_kernel
+    assert native.device_flags() == 0

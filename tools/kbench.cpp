@@ -110,6 +110,13 @@ static int cmd_conv(int argc, char** argv) {
         printf("  max|d| vs impl %d = %.3e (|ref|max %.2f, nonfinite %zu)", ref_impl, md, mx, nbad);
     }
     int32_t flags = 0; AK(adk_debug_flags(&flags));
+    {   // FNV-1a over the output bits: two builds / kernels that claim bit-identical results print the same value
+        std::vector<unsigned> ob(out_n);
+        CK(hipMemcpy(ob.data(), out, out_n * 4, hipMemcpyDeviceToHost));
+        unsigned long long h = 1469598103934665603ull;
+        for (unsigned v : ob) { h ^= v; h *= 1099511628211ull; }
+        printf("  out#%016llx", h);
+    }
     printf("  flags %d\n", flags);
     // debug builds of the library (-DADK_SK16_DBG=16) record an s_memtime timeline of one workgroup of the last launch
     typedef int (*trace_fn)(unsigned long long*, int);
@@ -143,6 +150,18 @@ static int cmd_conv(int argc, char** argv) {
             }
             printf("   mean: %5.0f %5.0f %5.0f %5.0f\n", s0 / n, s1 / n, s2 / n, s3 / n);
         }
+    }
+    if (trace_fn pf = (trace_fn)dlsym(RTLD_DEFAULT, "adk_debug_rp_trace")) {
+        std::vector<unsigned long long> tr(2 * 16 * 8);
+        if (pf(tr.data(), 2 * 16 * 8) == 0)
+            for (int wg = 0; wg < 2; ++wg) {
+                printf("  pipelined rows kernel, workgroup %d wave 0, 10 ns ticks per item: k loop | epilogue | left-over staging | barrier\n", wg ? 100 : 0);
+                for (int it = 0; it < 16; ++it) {
+                    const unsigned long long* t = &tr[(wg * 16 + it) * 8];
+                    if (!t[0] || !t[3]) break;
+                    printf("   item %2d (t = %5llu): %5llu %5llu %5llu %5lld\n", it, t[0] - tr[wg * 16 * 8], t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] ? (long long)(t[4] - t[3]) : -1ll);
+                }
+            }
     }
     if (trace_fn wf = (trace_fn)dlsym(RTLD_DEFAULT, "adk_debug_rl_wg_trace")) {
         std::vector<unsigned long long> tr(2048 * 4);
