@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_MARKER_N = 7654321                         # --pmc-markers: element count of the marker launches
 PMC_TRAFFIC_FILE = "r2_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench (tools/run_r2k.sh)
 PMC_TRAFFIC_SCRIPT = "tools/run_r3p.sh"
-PMC_TRAFFIC_COMMIT = "33351fd"                 # the commit those passes were taken at
+PMC_TRAFFIC_COMMIT = "8c9de12"                 # the commit those passes were taken at
 
 
 def build_audiodec(root, device, streams, max_frames, sd_bcast=False):
@@ -399,14 +399,26 @@ def extra_configs(root, dev, steps=100, warmup=10):
         return ad
 
     def timed(fn, n, w):
-        for _ in range(w):
+        """Seconds per call: warm-up of >= w calls AND >= 0.3 s (a freshly built model follows seconds of host-only work; the first
+        ~100 ms of GPU activity after that sporadically contain one stall of 30-80 ms -- tools/hiccup.py: never in steady state),
+        then five groups of n / 5 back-to-back calls, each bracketed by a synchronise: the median group."""
+        t_w = time.perf_counter()
+        i = 0
+        while i < w or time.perf_counter() - t_w < 0.3:
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
+            i += 1
+            if i % 16 == 0:
+                torch.cuda.synchronize()
+        per = max(1, n // 5)
+        groups = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(per):
+                fn()
+            torch.cuda.synchronize()
+            groups.append((time.perf_counter() - t0) / per)
+        return float(np.median(groups))
 
     def timed_median(fn, n, w):                    # one-shot latency: each call host-synchronised, median (a box hiccup of tens of ms in
         for _ in range(w):                         # one of 20 calls would otherwise be the whole number)
@@ -453,7 +465,7 @@ def extra_configs(root, dev, steps=100, warmup=10):
             os.environ.pop("ADK_VOCODER_STAGES", None)
         else:
             os.environ["ADK_VOCODER_STAGES"] = old_st
-    res["note"] = "one HIP stream, one program per model half; host-synchronised wall time over the timed steps"
+    res["note"] = "one HIP stream, one program per model half; host-synchronised wall time, median of five groups of steps after >= 0.3 s of warm-up"
     return res
 
 
