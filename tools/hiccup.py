@@ -16,11 +16,17 @@ def main():
         if os.environ.get("NOGC"):
             gc.disable()
         ts = []
+        if os.environ.get("SIDE"):                      # a non-default stream (HIP graphs cannot be captured on the legacy default one)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            torch.cuda.set_stream(side)
         for i in range(n):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             y = ad.decoder.decode(ad.rx_encoder.lookup(ad.tx_encoder.quantize(ad.tx_encoder.encode(x))))
             torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
         ts = np.asarray(ts)
+        st = [p.graph_stats() for p in [ad.tx_encoder._encoder()]] if hasattr(ad.tx_encoder._encoder(), "graph_stats") else None
+        print("graph stats (encoder):", st)
         print(f"{model} B={B}: median {np.median(ts):.3f} ms, p99 {np.percentile(ts, 99):.3f}, max {ts.max():.3f}; steps over 3x the median:",
               [(int(i), round(float(ts[i]), 2)) for i in np.nonzero(ts > 3 * np.median(ts))[0]][:20])
 
