@@ -304,7 +304,8 @@ int launch_rp(const ConvArgs& a, hipStream_t s, int tt) {
     const long long n_items = (long long)a.batch * rp.tiles_per_stream * a.groups;
     if (n_items > 0x7fffffffLL || lds > 160 * 1024) return fail(ADK_ERR_SHAPE, "conv: pipelined rows kernel does not fit");
     rp.n_items = (int)n_items;
-    const unsigned grid = (unsigned)std::min<long long>(n_items, 256);
+    const long long per_cu = std::max<long long>(1, std::min<long long>(160 * 1024 / (long long)lds, 2048 / (64 * NW)));   // resident workgroups per CU
+    const unsigned grid = (unsigned)std::min<long long>(n_items, 256 * per_cu);
     auto go = [&](auto kern) -> int {
         static bool attr_set_dev[kMaxDevices] = {};      // per instantiation and device
         bool& attr_set = attr_set_dev[current_device()];
@@ -322,14 +323,18 @@ int launch_rp(const ConvArgs& a, hipStream_t s, int tt) {
     return fail(ADK_ERR_ARG, "conv: unsupported input activation for the pipelined rows kernel");
 }
 
-// time tile: the whole call of a stream when two buffers of it fit, else the longest multiple of 32 that does
+int g_rp_buf_kb = -1;       // ADK_RP16_BUF_KB: LDS per row buffer (default 80: one workgroup per CU; 40: two, if the tiles allow)
+
+// time tile: the whole call of a stream when a buffer holds it, else the call cut into equal tiles (multiples of 32) that fit
 int rp16_time_tile(const ConvArgs& a) {
+    if (g_rp_buf_kb < 0) { const char* e = getenv("ADK_RP16_BUF_KB"); g_rp_buf_kb = (e && atoi(e) >= 8 && atoi(e) <= 80) ? atoi(e) : 80; }
     const int rs = 4 * a.cin_g + 16;
     const int span = (a.taps - 1) * a.dilation;
-    int tt = ((80 * 1024 / rs - span) / 32) * 32;
-    if (tt < 32) return 0;
-    if (tt >= a.t_out) tt = a.t_out;
-    return tt;
+    const int tt_max = ((g_rp_buf_kb * 1024 / rs - span) / 32) * 32;
+    if (tt_max < 32) return 0;
+    if (tt_max >= a.t_out) return a.t_out;
+    const int tiles = (a.t_out + tt_max - 1) / tt_max;
+    return std::min(tt_max, ((a.t_out + tiles - 1) / tiles + 31) / 32 * 32);
 }
 }  // namespace
 
