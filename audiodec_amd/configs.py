@@ -27,14 +27,14 @@ def _ae(strides=(3, 4, 5, 5), codebook_num=8, codec="audiodec", use_weight_norm=
     return p
 
 
-def _voc(kernel_sizes, groups, stats, dilations=None):
+def _voc(kernel_sizes, groups, stats, dilations=None, use_additional_convs=True):
     n = len(kernel_sizes)
     return dict(
         in_channels=64, out_channels=1, channels=512, kernel_size=7,
         upsample_scales=[5, 5, 4, 3], upsample_kernel_sizes=[10, 10, 8, 6],
         resblock_kernel_sizes=list(kernel_sizes),
         resblock_dilations=[[1, 3, 5] for _ in range(n)] if dilations is None else dilations,
-        groups=groups, bias=True, use_additional_convs=True,
+        groups=groups, bias=True, use_additional_convs=use_additional_convs,
         nonlinear_activation="LeakyReLU", nonlinear_activation_params={"negative_slope": 0.1},
         use_weight_norm=True, stats=stats,
     )
@@ -60,6 +60,13 @@ EXPERIMENTS = {
         "HiFiGAN", 48000, _voc([3], 3, "stats/symAD_vctk_48000_hop300_clean.npy")),
     "vocoder/AudioDec_v3_symADuniv_vctk_48000_hop300_clean": (
         "UnivNet", 48000, _voc([11], 3, "stats/symADuniv_vctk_48000_hop300_clean.npy")),
+    # NOT in the reference's exp/: the generator option no released config switches off (HiFiGANResidualBlock
+    # use_additional_convs=False, modules/residual_block.py:93-106: x + convs1(act(x)) without the second conv), as v1- and
+    # v0-shaped vocoders, so that the lowering of that branch has reference fixtures too (EXTRA_ALIASES below)
+    "vocoder/test_v1_noaddl_symAD_vctk_48000_hop300": (
+        "HiFiGAN", 48000, _voc([11], 3, "stats/symAD_vctk_48000_hop300_clean.npy", use_additional_convs=False)),
+    "vocoder/test_v0_noaddl_symAD_vctk_48000_hop300": (
+        "HiFiGAN", 48000, _voc([3, 7, 11], 1, "stats/symAD_vctk_48000_hop300_clean.npy", use_additional_convs=False)),
 }
 
 
@@ -98,15 +105,35 @@ _ALIASES = {
 }
 
 
+# Model names that are NOT the reference's (its assign_model raises for them, and so does ours): test models for generator options
+# no released alias exercises.  configs.alias / checkpoint_paths / synth.write_model know them; assign_model does not.
+EXTRA_ALIASES = {
+    "test_v1_noaddl": (48000, "autoencoder/symAD_vctk_48000_hop300", 200000,
+                       "vocoder/test_v1_noaddl_symAD_vctk_48000_hop300", 500000),
+    "test_v0_noaddl": (48000, "autoencoder/symAD_vctk_48000_hop300", 200000,
+                       "vocoder/test_v0_noaddl_symAD_vctk_48000_hop300", 500000),
+}
+
+
 def alias(model):
-    if model not in _ALIASES:
-        raise NotImplementedError(f"Model {model} is not supported!")
-    return _ALIASES[model]
+    if model in _ALIASES:
+        return _ALIASES[model]
+    if model in EXTRA_ALIASES:
+        return EXTRA_ALIASES[model]
+    raise NotImplementedError(f"Model {model} is not supported!")
 
 
-def assign_model(model):
-    """(sample_rate, encoder_checkpoint, decoder_checkpoint) with cwd-relative 'exp/...' paths."""
+def checkpoint_paths(model):
+    """(sample_rate, encoder_checkpoint, decoder_checkpoint) with cwd-relative 'exp/...' paths, for the reference's aliases and
+    for EXTRA_ALIASES."""
     sample_rate, enc_tag, tx_steps, dec_tag, rx_steps = alias(model)
     encoder_checkpoint = os.path.join("exp", *enc_tag.split("/"), f"checkpoint-{tx_steps}steps.pkl")
     decoder_checkpoint = os.path.join("exp", *dec_tag.split("/"), f"checkpoint-{rx_steps}steps.pkl")
     return sample_rate, encoder_checkpoint, decoder_checkpoint
+
+
+def assign_model(model):
+    """utils/audiodec.py:109-179: the reference's 11 names, NotImplementedError for anything else."""
+    if model not in _ALIASES:
+        raise NotImplementedError(f"Model {model} is not supported!")
+    return checkpoint_paths(model)

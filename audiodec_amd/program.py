@@ -358,9 +358,7 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
     multigroup = arch.hifigan_is_multigroup(p)
     groups = p.get("groups", 1)
     ch = p.get("channels", 512)
-    addl = p.get("use_additional_convs", True)
-    if not addl:
-        raise NotImplementedError("use_additional_convs=False is not lowered")
+    addl = p.get("use_additional_convs", True)       # False: x + convs1(act(x)), no second conv (residual_block.py:100-105)
     n_up = len(p["upsample_scales"])
     if part is not None:
         if not cuts or sorted(set(cuts)) != list(cuts) or cuts[0] <= 0 or cuts[-1] >= n_up or not 0 <= part <= len(cuts):
@@ -393,10 +391,14 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
             # materialised -- the first conv and the first residual read the same C channels per group
             x, gs_in, gs_res = x0, 0, 0
             for j in range(len(p["resblock_dilations"][0])):
-                xt = b.ring(c * groups, 0, rate)
-                b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
-                nx = b.ring(c * groups, 0, rate)
-                b.conv(f"blocks.{i}.convs2.{j}", xt, nx, act, slope, res_ring=x, res_group_stride=gs_res)
+                if addl:
+                    xt = b.ring(c * groups, 0, rate)
+                    b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
+                    nx = b.ring(c * groups, 0, rate)
+                    b.conv(f"blocks.{i}.convs2.{j}", xt, nx, act, slope, res_ring=x, res_group_stride=gs_res)
+                else:
+                    nx = b.ring(c * groups, 0, rate)
+                    b.conv(f"blocks.{i}.convs1.{j}", x, nx, act, slope, in_group_stride=gs_in, res_ring=x, res_group_stride=gs_res)
                 x, gs_in, gs_res = nx, None, None
             b.conv(f"blocks.{i}.conv_out", x, cur)
         else:
@@ -405,10 +407,14 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
             for bi, dil in enumerate(p["resblock_dilations"]):
                 x = x0
                 for j in range(len(dil)):
-                    xt = b.ring(c, 0, rate)
-                    b.conv(f"blocks.{i}.blocks.{bi}.convs1.{j}", x, xt, act, slope)
-                    nx = b.ring(c, 0, rate)
-                    b.conv(f"blocks.{i}.blocks.{bi}.convs2.{j}", xt, nx, act, slope, res_ring=x)
+                    if addl:
+                        xt = b.ring(c, 0, rate)
+                        b.conv(f"blocks.{i}.blocks.{bi}.convs1.{j}", x, xt, act, slope)
+                        nx = b.ring(c, 0, rate)
+                        b.conv(f"blocks.{i}.blocks.{bi}.convs2.{j}", xt, nx, act, slope, res_ring=x)
+                    else:
+                        nx = b.ring(c, 0, rate)
+                        b.conv(f"blocks.{i}.blocks.{bi}.convs1.{j}", x, nx, act, slope, res_ring=x)
                     x = nx
                 outs.append(x)
             b.mean(outs, cur)

@@ -46,7 +46,10 @@ def import_reference():
 
 
 def load_reference(ref_audiodec, model):
-    sr, enc_ckpt, dec_ckpt = ref_audiodec.assign_model(model)
+    if model in configs.EXTRA_ALIASES:            # test models for generator options no released alias has: the reference's
+        sr, enc_ckpt, dec_ckpt = configs.checkpoint_paths(model)      # loaders take any checkpoint path (bin/stream.py:56-77)
+    else:
+        sr, enc_ckpt, dec_ckpt = ref_audiodec.assign_model(model)
     ad = ref_audiodec.AudioDec(tx_device="cpu", rx_device="cpu")
     ad.load_transmitter(enc_ckpt)
     ad.load_receiver(enc_ckpt, dec_ckpt)
@@ -72,7 +75,7 @@ def build_oracle(model, batch):
 def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
     torch.set_num_threads(4)
     sr, ad = load_reference(ref_audiodec, model)
-    hop = ad.get_hop_length(ref_audiodec.assign_model(model)[1])
+    hop = ad.get_hop_length(configs.checkpoint_paths(model)[1])
     total = one_shot_len if one_shot_len is not None else sum(schedule) * hop
     chunks = [one_shot_len] if one_shot_len is not None else [c * hop for c in schedule]
     audio = np.stack([synth.synth_audio(SEED, s, total) for s in range(n_streams)])
@@ -250,6 +253,9 @@ CASES = {
     "vctk_denoise_stream": ("vctk_denoise", 1, [1, 2], None),
     "vctk_univ_stream": ("vctk_univ", 1, [1, 2], None),
     "vctk_univ_sym_stream": ("vctk_univ_sym", 1, [2, 1], None),
+    # HiFiGANResidualBlock(use_additional_convs=False) (residual_block.py:100-105), grouped (v1-shaped) and MRF (v0-shaped)
+    "test_v1_noaddl_stream": ("test_v1_noaddl", 2, [1, 2, 1], None),
+    "test_v0_noaddl_stream": ("test_v0_noaddl", 1, [1, 2], None),
 }
 
 

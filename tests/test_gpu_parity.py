@@ -26,7 +26,8 @@ def _load(golden_dir, name):
 
 
 def load_audiodec(ckpt_root, model, seed, num_streams, max_frames, split16=False):
-    from audiodec_amd.audiodec import AudioDec, assign_model
+    from audiodec_amd.audiodec import AudioDec
+    from audiodec_amd.configs import checkpoint_paths as assign_model      # also knows the EXTRA_ALIASES test models
     synth.write_model(ckpt_root, model, seed)
     cwd = os.getcwd()
     os.chdir(ckpt_root)          # the reference's paths are cwd-relative ('exp/...', 'stats/...')
@@ -256,7 +257,8 @@ def run_hip(ad, audio, chunks):
 @pytest.mark.parametrize("name,max_frames", [("vctk_sym_stream", 2), ("vctk_v1_stream", 4), ("libritts_sym_file", 16),
                                              ("vctk_v2_stream", 2), ("vctk_v0_stream", 2), ("vctk_activate_sym_stream", 2),
                                              ("vctk_c16h320_sym_stream", 2), ("libritts_v1_stream", 2), ("vctk_denoise_stream", 2),
-                                             ("vctk_univ_stream", 2), ("vctk_univ_sym_stream", 2)])
+                                             ("vctk_univ_stream", 2), ("vctk_univ_sym_stream", 2),
+                                             ("test_v1_noaddl_stream", 2), ("test_v0_noaddl_stream", 2)])
 @pytest.mark.parametrize("split16", [False, True], ids=["f32", "split16"])
 def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames, split16):
     g = _load(golden_dir, name)

@@ -202,3 +202,18 @@ def test_streamer_runtime_tick_latency_rule_and_dumps(tmp_path):
     assert fs == 8000 and a.shape[0] == 24
     fs, b = wavfile.read(str(tmp_path / "out.wav"))
     assert b.shape[0] == 24 and b.max() == 32767                 # 1.125 clipped to full scale
+
+
+def test_extra_aliases_are_not_reference_names():
+    """configs.EXTRA_ALIASES (test models for generator options no released alias uses) resolve through alias / checkpoint_paths but
+    NOT through assign_model, which keeps the reference's table and error (utils/audiodec.py:109-179)."""
+    from audiodec_amd import configs, arch
+    for name in configs.EXTRA_ALIASES:
+        sr, enc, dec = configs.checkpoint_paths(name)
+        assert dec.startswith("exp/vocoder/test_")
+        with pytest.raises(NotImplementedError):
+            configs.assign_model(name)
+        _, _, _, dec_tag, _ = configs.alias(name)
+        _, _, p = configs.experiment(dec_tag)
+        assert p["use_additional_convs"] is False
+        assert not any(".convs2." in s.name for s in arch.hifigan_convs(p))

@@ -77,7 +77,8 @@ def explain_flips(idx, ref_idx, margin, what):
 
 CASES = ["vctk_sym_stream", "vctk_v1_stream", "libritts_sym_file", "vctk_v0_stream", "vctk_v2_stream",
          "vctk_activate_sym_stream", "vctk_c16h320_sym_stream", "libritts_v1_stream", "vctk_denoise_stream",
-         "vctk_univ_stream", "vctk_univ_sym_stream"]          # all 11 aliases of utils/audiodec.py:109-179
+         "vctk_univ_stream", "vctk_univ_sym_stream",          # all 11 aliases of utils/audiodec.py:109-179
+         "test_v1_noaddl_stream", "test_v0_noaddl_stream"]    # + use_additional_convs=False (configs.EXTRA_ALIASES)
 
 
 @pytest.mark.parametrize("name", CASES)
