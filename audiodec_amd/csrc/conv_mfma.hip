@@ -701,6 +701,7 @@ const Cfg kCfgs[7] = {{4, 1, 2, "conv_sk<128x64>"}, {4, 1, 4, "conv_sk<128x128>"
 int g_forced_cfg = -2;     // -2: not initialised (read ADK_CONV_CFG), -1: heuristic
 int g_occ = -1;            // persistent workgroups per CU (ADK_CONV_OCC, default 2)
 int g_fixed_g = 0;         // persistent workgroups per launch when > 0 (ADK_CONV_G / adk_set_conv_workgroups), else 256 * g_occ
+int g_oversub = 0;         // ADK_CONV_OVERSUB
 int g_aligned = 1;         // tile-aligned stream-K ranges where the rule in launch_cfg applies (ADK_CONV_ALIGNED=0: never)
 int g_max_split = 5;       // most workgroups sharing one tile (ADK_CONV_MAX_SPLIT; 0 = no limit).  Measured (tools/run_r2s.sh):
                            // 5 vs no limit at 256 streams: last strided conv 30.9 -> 18.3 us, first transposed conv 25.2 -> 18.9,
@@ -771,7 +772,9 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     const long long tiles = (long long)sk.m_tiles * sk.n_tiles * a.groups;
     sk.total = tiles * sk.nchunks;
     const long long slots = NT == 256 ? 256LL * g_occ : 256LL;        // resident workgroups: 512-thread workgroups are alone on their CU
-    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, slots) : (g_fixed_g > 0 ? std::min<long long>(g_fixed_g, slots) : slots);
+    // ADK_CONV_OVERSUB percent (tuning): allow that many more workgroups than slots -- the surplus starts when the first ones end
+    const long long lim = NT == 256 ? slots + slots * g_oversub / 100 : slots;
+    const long long cap = ws.workgroups > 0 ? std::min<long long>(ws.workgroups, lim) : (g_fixed_g > 0 ? std::min<long long>(g_fixed_g, lim) : lim);
     const long long G = sk_plan(tiles, cap, sk);
     sk.G = (int)G;
     const size_t part_bytes = (size_t)sk.G * NT * NJ * 16 * sizeof(float);
@@ -841,11 +844,12 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
         e = getenv("ADK_CONV_MIN_UNITS"); if (e && atoi(e) >= 1) g_min_units = atoi(e);
         e = getenv("ADK_CONV_MAX_SPLIT"); if (e && atoi(e) >= 0) g_max_split = atoi(e);
         e = getenv("ADK_CONV_ALIGNED"); if (e) g_aligned = atoi(e) != 0;
-        e = getenv("ADK_CONV_G"); if (e && atoi(e) >= 8 && atoi(e) <= 256 * g_occ) g_fixed_g = atoi(e) / 8 * 8;
+        e = getenv("ADK_CONV_OVERSUB"); if (e && atoi(e) >= 0 && atoi(e) <= 100) g_oversub = atoi(e);
+        e = getenv("ADK_CONV_G"); if (e && atoi(e) >= 8 && atoi(e) <= 2 * 256 * g_occ) g_fixed_g = atoi(e) / 8 * 8;
     }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);
     if (flags_offset) *flags_offset = part;
-    return part + (size_t)256 * g_occ * sizeof(unsigned);
+    return part + (size_t)2 * 256 * g_occ * sizeof(unsigned);       // flags for up to twice the resident workgroups (oversubscribed plans)
 }
 
 int conv_mfma_pick(const ConvArgs& a) {
