@@ -217,3 +217,50 @@ def test_extra_aliases_are_not_reference_names():
         _, _, p = configs.experiment(dec_tag)
         assert p["use_additional_convs"] is False
         assert not any(".convs2." in s.name for s in arch.hifigan_convs(p))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r2_bench_latest.json is one JSON line of bench.py on an MI355X: the keys the driver and the judge read are there, the
+    metric / unit are BASELINE.json's, `value` is consistent with `ms_per_step`, roofline.frac = achieved / peak."""
+    import json
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    line = open(os.path.join(root, "profiles", "r2_bench_latest.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and "frames/s" in base["metric"] and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    frames = d["config"]["streams_total"] * d["config"]["frames_per_step_per_stream"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) / d["value"] < 2e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.5
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["self_check"]["ok"] is True and d["device_error_flags"] == 0
+
+
+def test_pmc_summary_keeps_only_the_marked_region(tmp_path):
+    """tools/pmc_summary.py: dispatches between the two `bench.py --pmc-markers` launches (the largest-grid arange kernel, exactly
+    twice) are the steady state; everything else (model load, warm-up) is dropped; FETCH_SIZE is doubled (gfx950 correction)."""
+    import subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    hdr = '"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n'
+    def row(i, grid, name, counter, val):
+        return f'{i},{i},"Agent 2",1,1,1,{grid},1,"{name}",256,0,0,4,0,16,"{counter}",{val},0,0\n'
+    k = "void adk::conv_sk_kernel<2, 2, 1, 2, true, 1>(adk::ConvArgs, adk::SkArgs)"
+    ar = "void at::native::elementwise_kernel_with_index<int, at::native::arange_cuda_out>"
+    for counter, base in (("FETCH_SIZE", 100.0), ("WRITE_SIZE", 10.0)):
+        d = tmp_path / f"pmc_{counter}" / "x"
+        d.mkdir(parents=True)
+        rows = [row(1, 256, ar, counter, 1), row(2, 122880, k, counter, 9 * base),          # load / warm-up: small arange, a big launch
+                row(3, 7654400, ar, counter, 1), row(4, 122880, k, counter, base), row(5, 122880, k, counter, 3 * base),
+                row(6, 7654400, ar, counter, 1), row(7, 122880, k, counter, 9 * base)]
+        (d / "p_counter_collection.csv").write_text(hdr + "".join(rows))
+    out = tmp_path / "out.csv"
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(tmp_path), str(out)], stdout=subprocess.DEVNULL)
+    lines = out.read_text().splitlines()
+    assert lines[0].startswith("# region: launches between the two")
+    assert lines[2] == '"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,2,200,400,20'
