@@ -317,7 +317,6 @@ int launch_rp(const ConvArgs& a, hipStream_t s, int tt) {
         ADK_HIP_CHECK(hipGetLastError());
         return ADK_OK;
     };
-    if (a.act_in == ADK_ACT_ELU) return go(conv_rp16_kernel<C, ADK_ACT_ELU, 11, NW>);
     if (a.act_in == ADK_ACT_LEAKY) return go(conv_rp16_kernel<C, ADK_ACT_LEAKY, 11, NW>);
     if (a.act_in == ADK_ACT_NONE) return go(conv_rp16_kernel<C, ADK_ACT_NONE, 11, NW>);
     return fail(ADK_ERR_ARG, "conv: unsupported input activation for the pipelined rows kernel");
@@ -343,6 +342,7 @@ bool conv_rp16_pick(const ConvArgs& a, bool force) {
     if (g_rp_enable < 0) { const char* e = getenv("ADK_CONV_RP16"); g_rp_enable = e ? atoi(e) : 0; }
     if (!g_rp_enable && !force) return false;
     if (!conv_rl16_supported(a) || a.taps != 11 || a.up != 1) return false;
+    if (a.act_in != ADK_ACT_LEAKY && a.act_in != ADK_ACT_NONE) return false;       // the K11 layers of the path are the vocoder's (LeakyReLU)
     if ((unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull >= 0x80000000ull) return false;       // 32-bit byte offsets of the staging loads
     const int tt = rp16_time_tile(a);
     if (tt <= 0) return false;
