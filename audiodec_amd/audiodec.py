@@ -27,9 +27,11 @@ class AudioDec(AudioCodec):
         num_streams: int = 1,
         max_frames: int = 16,
     ):
+        # The signature keeps the reference's 'cpu' defaults (utils/audiodec.py:20-30) so that callers port unchanged, but
+        # this package has no CPU compute path: 'cpu' becomes the first HIP device (with a warning), and without a HIP
+        # device the constructor fails here, not at the first kernel launch.
+        tx_device, rx_device = native.resolve_device(tx_device), native.resolve_device(rx_device)
         super(AudioDec, self).__init__(tx_device=tx_device, rx_device=rx_device, receptive_length=receptive_length)
-        # The signature keeps the reference's 'cpu' defaults (utils/audiodec.py:20-30) so that keyword callers port
-        # unchanged, but this package has no CPU compute path: say so here, not at the first kernel launch.
         for d in (tx_device, rx_device):
             native.require_gpu(d)
         self.num_streams = num_streams
@@ -100,6 +102,7 @@ class AudioDecStreamer(AudioCodecStreamer):
         decoder=None,
         rx_device: str = "cpu",
     ):
+        tx_device, rx_device = native.resolve_device(tx_device), native.resolve_device(rx_device)
         super(AudioDecStreamer, self).__init__(
             input_device=input_device, output_device=output_device, input_channels=input_channels,
             output_channels=output_channels, frame_size=frame_size, sample_rate=sample_rate, gain=gain,

@@ -71,16 +71,10 @@ int launch_conv_rl(const ConvArgs& a, hipStream_t s);
 bool conv_rl16_supported(const ConvArgs& a);        // split-f16 rows-in-LDS kernel (wfrag = adk_pack_weights_split16 layout)
 bool conv_rl16_preferred(const ConvArgs& a);
 int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
-bool conv_rp16_pick(const ConvArgs& a, bool force);   // pipelined rows kernel (conv_rp16.hip): persistent workgroups, next item's rows staged under the MFMAs
-int launch_conv_rp16(const ConvArgs& a, hipStream_t s);
 bool conv_rl16_fusable(const ConvArgs& a1, const ConvArgs& a2);      // residual unit (K7 conv -> 1x1 + residual) as one launch
 int launch_conv_rl16_fused(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s);   // ADK_ERR_STATE: not fusable for this call
 bool conv_up16_supported(const ConvArgs& a);        // streaming kernel of the last up-sampling stage (64 -> s*Cout <= 96 rows, 2 taps)
 int launch_conv_up16(const ConvArgs& a, hipStream_t s);
-int conv_gk16_pick(const ConvArgs& a, bool force = false);              // big-tile split-f16 stream-K for the deep layers: 0 = not taken, 1 = 256x128, 2 = 128x256, 3 = 128x128
-int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws, bool force = false);
-bool conv_bk16_pick(const ConvArgs& a, bool force = false);          // register-staged 128x128 tiles (64x64 per wave) for the many-tile deep layers
-int launch_conv_bk16(const ConvArgs& a, hipStream_t s, Workspace& ws);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
 int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);

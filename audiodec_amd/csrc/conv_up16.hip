@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv_up16_kernel(ConvArgs a, UpArgs u)
     }
     __builtin_amdgcn_sched_barrier(0);                      // nothing below (the conversion of xr) may move above the DMA issue
     if (tid < 32 * MT) blds[tid] = bias_v;
-    __syncthreads();                                        // drains the LDS-DMA (and the loads above: one round trip for all)
+    // every wave's LDS-DMA slice is read by the OTHER waves: drain this wave's VM-counted DMA explicitly before the barrier that
+    // publishes it (hipcc 7.2 happens to emit the wait for the workgroup fence; the fence does not formally promise it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the weights of all waves are in LDS (and the loads above have landed: one round trip for all)
     if (!live) return;
 
     f16x8u bh[UP_KSTEPS], bl[UP_KSTEPS];

@@ -74,8 +74,7 @@ static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel
 static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
 
 static bool is_split16(int impl) {
-    return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP ||
-           impl == ADK_IMPL_SPLIT16_GK || impl == ADK_IMPL_SPLIT16_BK || impl == ADK_IMPL_SPLIT16_PIPE;
+    return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
 }
 static void read_env() {
     if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
@@ -96,24 +95,13 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
             return fail(ADK_ERR_SHAPE, "conv: the up-sampling streamer takes 2-tap transposed convs with 64 input channels and <= 96 GEMM rows");
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a)))
             return launch_conv_up16(a, s);
-        if (impl == ADK_IMPL_SPLIT16_PIPE) {
-            if (!conv_rp16_pick(a, true)) return fail(ADK_ERR_SHAPE, "conv: the pipelined rows kernel takes the 11-tap layers of the rows-in-LDS kernel");
-            return launch_conv_rp16(a, s);
-        }
         if (impl == ADK_IMPL_SPLIT16_ROWS && !conv_rl16_supported(a))
             return fail(ADK_ERR_SHAPE, "conv: split-f16 rows-in-LDS kernel needs stride 1, 32/64 channels per group, K in {3,7,11}, split16 w_frag");
         if (impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a)))
-            return (impl == ADK_IMPL_SPLIT16 && conv_rp16_pick(a, false)) ? launch_conv_rp16(a, s) : launch_conv_rl16(a, s);
+            return launch_conv_rl16(a, s);
         if (!ok) return fail(ADK_ERR_SHAPE, "conv: split-f16 kernel needs w_frag, cin_g % 32 == 0 and 16-byte aligned rows");
         int rc = ensure_workspace(ws);
         if (rc != ADK_OK) return rc;
-        if (impl == ADK_IMPL_SPLIT16_GK) return launch_conv_gk16(a, s, ws, true);
-        if (impl == ADK_IMPL_SPLIT16_BK) {
-            if (!conv_bk16_pick(a, true)) return fail(ADK_ERR_SHAPE, "conv: the 128x128 kernel needs cin_g % 32 == 0 and >= 128 output channels per group");
-            return launch_conv_bk16(a, s, ws);
-        }
-        if (impl == ADK_IMPL_SPLIT16 && conv_bk16_pick(a)) return launch_conv_bk16(a, s, ws);
-        if (impl == ADK_IMPL_SPLIT16 && conv_gk16_pick(a)) return launch_conv_gk16(a, s, ws);
         return launch_conv_sk16(a, s, ws);
     }
     const bool want_mfma = (impl == ADK_IMPL_MFMA) || (impl == ADK_IMPL_AUTO && ok && a.groups * a.cout_g >= 32);
@@ -136,14 +124,7 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
     if (is_split16(impl)) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
-        if (impl == ADK_IMPL_SPLIT16_PIPE || (rows && impl == ADK_IMPL_SPLIT16 && conv_rp16_pick(a, false))) return a.cin_g == 32 ? "conv_rp16<32>" : "conv_rp16<64>";
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
-        if ((impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_BK) && conv_mfma_supported(a) && conv_bk16_pick(a, impl == ADK_IMPL_SPLIT16_BK))
-            return "conv_bk16<128x128>";
-        if ((impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_GK) && conv_mfma_supported(a)) {
-            const int gk = conv_gk16_pick(a, impl == ADK_IMPL_SPLIT16_GK);
-            if (gk) return gk == 1 ? "conv_gk16<256x128>" : (gk == 2 ? "conv_gk16<128x256>" : "conv_gk16<128x128>");
-        }
         return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
     }
     const bool mf = impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (impl == ADK_IMPL_MFMA || impl == ADK_IMPL_MFMA_ROWS || a.groups * a.cout_g >= 32);
@@ -536,7 +517,8 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
                 int rc = ADK_OK;
                 hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(p->ws.ptr) + p->ws.flags_offset, 0, p->ws.bytes - p->ws.flags_offset, s);
                 if (e != hipSuccess) rc = fail(ADK_ERR_HIP, std::string("graph capture: memset: ") + hipGetErrorString(e));
-                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK;) { int used = 1; rc = run_op(p, k, frames, ext, s, &used); k += used; }
+                // (no fusion across the end of the captured range: op g_hi touches a caller buffer whose pointer would be baked into the graph)
+                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK;) { int used = 1; rc = run_op(p, k, frames, ext, s, k + 1 < p->g_hi ? &used : nullptr); k += used; }
                 e = hipStreamEndCapture(s, &g);
                 if (rc != ADK_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
                 if (e != hipSuccess || !g) return fail(ADK_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));

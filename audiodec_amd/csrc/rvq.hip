@@ -400,16 +400,25 @@ extern "C" int adk_ring_write(const float* src, adk_ring_view ring, const float*
     return ADK_OK;
 }
 
+// read AND clear in one atomic operation on the device: a bit set by a kernel of another HIP stream or host thread between a
+// separate read and a separate clear would be lost
+__global__ void flags_fetch_clear_kernel(int* out) { *out = atomicExch(&g_adk_flags, 0); }
+
 extern "C" int adk_debug_flags(int32_t* out) {
-    // OR of the flag words of every device this library has launched on (plus the current one); each is cleared
+    // OR of the flag words of every device this library has launched on (plus the current one); each is fetched and cleared
+    // by one atomicExch after everything queued on that device has finished
+    static int* scratch[kMaxDevices] = {};
     int all = 0;
     const int here = current_device();
     for (int d = 0; d < kMaxDevices; ++d) {
         if (!g_flag_ptr[d] && d != here) continue;
         DeviceGuard guard(d);
-        int v = 0, zero = 0;
-        ADK_HIP_CHECK(hipMemcpyFromSymbol(&v, HIP_SYMBOL(adk::g_adk_flags), sizeof(int)));
-        if (v) ADK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(adk::g_adk_flags), &zero, sizeof(int)));
+        if (!scratch[d]) ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch[d]), sizeof(int)));
+        ADK_HIP_CHECK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(flags_fetch_clear_kernel, dim3(1), dim3(1), 0, nullptr, scratch[d]);
+        ADK_HIP_CHECK(hipGetLastError());
+        int v = 0;
+        ADK_HIP_CHECK(hipMemcpy(&v, scratch[d], sizeof(int), hipMemcpyDeviceToHost));
         all |= v;
     }
     if (out) *out = all;

@@ -78,7 +78,7 @@ class _CausalBase:
         d.act_in, d.act_in_slope, d.act_out = self.act_in, self.slope, self.act_out
         d.w = self.w_packed.data_ptr()
         d.w_frag = self.w_frag.data_ptr() if self.w_frag is not None else None
-        if self.impl in (native.IMPL_SPLIT16, native.IMPL_SPLIT16_ROWS, native.IMPL_SPLIT16_SK, native.IMPL_SPLIT16_UP, native.IMPL_SPLIT16_GK, native.IMPL_SPLIT16_BK, native.IMPL_SPLIT16_PIPE):
+        if self.impl in (native.IMPL_SPLIT16, native.IMPL_SPLIT16_ROWS, native.IMPL_SPLIT16_SK, native.IMPL_SPLIT16_UP):
             if getattr(self, "w_split", None) is None:
                 raise ValueError("this layer shape has no split-f16 kernel")
             d.w_frag = self.w_split.data_ptr()

@@ -13,7 +13,7 @@ ABI_VERSION = 8
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
-IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS, IMPL_SPLIT16, IMPL_SPLIT16_ROWS, IMPL_SPLIT16_SK, IMPL_SPLIT16_UP, IMPL_SPLIT16_GK, IMPL_SPLIT16_BK, IMPL_SPLIT16_PIPE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS, IMPL_SPLIT16, IMPL_SPLIT16_ROWS, IMPL_SPLIT16_SK, IMPL_SPLIT16_UP = 0, 1, 2, 3, 4, 5, 6, 7
 OP_CONV, OP_RING_WRITE, OP_MEAN, OP_HIST_REPLICATE = 0, 1, 2, 3
 
 
@@ -170,3 +170,26 @@ def require_gpu(device):
         raise NativeError("no HIP device visible (torch.cuda.is_available() is False)")
     lib()
     return dev
+
+
+_warned_cpu = False
+
+
+def resolve_device(device):
+    """Device string a facade object should live on.  The reference's constructors default to 'cpu' and its demos pass
+    'cpu' unless --cuda is given (utils/audiodec.py:20-30, demoFile.py:32-37); this package computes on HIP devices only.
+    So that such callers port unchanged, 'cpu' is mapped to the first HIP device with a one-time warning when one is
+    visible; without a HIP device it is an error (there is no CPU fallback)."""
+    import warnings
+    import torch
+    global _warned_cpu
+    dev = torch.device(device)
+    if dev.type != "cpu":
+        return str(device)
+    if not torch.cuda.is_available():
+        raise NativeError(f"device {device!r}: the AudioDec HIP path needs a HIP device ('cuda:N') and none is visible; "
+                          "there is no CPU implementation in this package")
+    if not _warned_cpu:
+        warnings.warn("audiodec_amd has no CPU compute path: device 'cpu' is mapped to 'cuda:0' (the first HIP device)", UserWarning, stacklevel=3)
+        _warned_cpu = True
+    return "cuda:0"

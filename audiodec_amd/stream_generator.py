@@ -366,7 +366,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
         return zq
 
     # ---- bit-packed transport (audiodec_amd/wire.py; the reference has no wire format) ----
-    def pack(self, idx, check=True):
+    def pack(self, idx, check=False):
         """Emitted indices -> uint8 payload (B, T, n_q*bits/8): 10 bytes per frame for 8 x 1024 codes."""
         from . import wire
         return wire.pack_codes(idx.to(self._dev()), self.size, check)

@@ -22,12 +22,14 @@ def frame_bytes(n_q, codebook_size):
     return (n_q * code_bits(codebook_size) + 7) // 8
 
 
-def pack_codes(idx, codebook_size=1024, check=True):
+def pack_codes(idx, codebook_size=1024, check=False):
     """idx (n_q, T) or (n_q, B, T) int64 on a HIP device -> uint8 payload (B, T, frame_bytes).
 
-    check=True (default) synchronises and raises ValueError if an index was not a code of its stage (the payload is
-    about to leave the device anyway); check=False leaves the failure in the sticky device flags
-    (native.raise_on_device_flags)."""
+    Asynchronous by default: an index that is not a code of its stage is packed as code 0 and recorded in the sticky
+    device flags, which the caller's next synchronisation point turns into the exception (native.raise_on_device_flags:
+    streamer ticks, demoFile, the offline drivers).  check=True does that here: it SYNCHRONISES the device and raises on
+    any pending device flag (not only this call's) -- for one-off calls whose payload leaves the device right away, never
+    inside a real-time tick."""
     dev = native.require_gpu(idx.device)
     if idx.dim() == 2:
         idx = idx.unsqueeze(1)

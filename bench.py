@@ -469,6 +469,27 @@ def extra_configs(root, dev, steps=100, warmup=10):
     return res
 
 
+def self_launch(n):
+    """Re-exec this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (rendezvous on
+    127.0.0.1, a free port) and return its exit code.  Fewer than n visible HIP devices is an error (rc 2) unless the
+    one-GPU rehearsal hook ADK_BENCH_ONE_GPU=1 is set (tests: every rank on cuda:0 over gloo)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("ADK_BENCH_ONE_GPU") != "1":
+        print(f"bench.py --gpus {n}: only {have} HIP device(s) visible", file=sys.stderr)
+        return 2
+    import __graft_entry__
+    __graft_entry__.build()                       # once, before the ranks start (they would serialise on the build lock)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -501,6 +522,11 @@ def main():
     ap.add_argument("--dump-ops", type=str, default=None, help="write the per-op HIP-event table (CSV) here")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches its own N ranks (one process per GPU over RCCL) and relays their exit code;
+        # under torchrun (WORLD_SIZE set, the driver's form for N > 1) this branch is not taken
+        sys.exit(self_launch(args.gpus))
+
     import __graft_entry__
     __graft_entry__.build()
     os.environ["ADK_SPLIT16"] = "1" if args.precision == "split16" else "0"    # read by the generators at construction
@@ -510,7 +536,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # test hook (not used by the driver): ADK_BENCH_BACKEND=gloo ADK_BENCH_ONE_GPU=1 runs all ranks on cuda:0 so the

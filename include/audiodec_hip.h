@@ -53,15 +53,7 @@ enum { ADK_IMPL_AUTO = 0, ADK_IMPL_DIRECT = 1, ADK_IMPL_MFMA = 2 /* stream-K imp
        ADK_IMPL_SPLIT16 = 4, ADK_IMPL_SPLIT16_ROWS = 5, ADK_IMPL_SPLIT16_SK = 6,
        /* the streaming kernel of the last up-sampling stage (fused activation -> ConvTranspose1d 64 -> Cout, s*Cout <= 96,
           + bias; HiFiGAN.py:285-289): SPLIT16 picks it for that layer shape, this value forces it */
-       ADK_IMPL_SPLIT16_UP = 7,
-       /* the opt-in big-tile LDS-DMA stream-K kernel (csrc/conv_gk16.hip; measured slower than SPLIT16_SK, kept as an experiment) */
-       ADK_IMPL_SPLIT16_GK = 8,
-       /* the register-staged 128x128-tile stream-K kernel (csrc/conv_bk16.hip): SPLIT16 picks it for the layers with many tiles
-          and long K (the grouped K11 convs of vocoder stages 0-1), this value forces it */
-       ADK_IMPL_SPLIT16_BK = 9,
-       /* the pipelined rows-in-LDS kernel (csrc/conv_rp16.hip: persistent workgroups, the next item's rows staged under the
-          MFMAs; K11 layers of SPLIT16_ROWS, bit-identical to it; measured no faster -- an experiment, also ADK_CONV_RP16=1) */
-       ADK_IMPL_SPLIT16_PIPE = 10 };
+       ADK_IMPL_SPLIT16_UP = 7 };
 
 const char* adk_last_error(void);
 int adk_abi_version(void);

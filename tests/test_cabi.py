@@ -79,6 +79,10 @@ def test_product_fails_loudly_without_gpu():
         m = AutoEncoderStreamGenerator().to("cuda:0")
         with pytest.raises(native.NativeError):
             m.initial_encoder(8192, "cuda:0")
+        # the reference's default devices ('cpu'): mapped to the first HIP device when there is one, an error when there is none
+        from audiodec_amd.audiodec import AudioDec
+        with pytest.raises(native.NativeError, match="no CPU implementation"):
+            AudioDec()
 
 
 def test_missing_library_is_an_error(monkeypatch, tmp_path):

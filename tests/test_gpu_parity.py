@@ -449,8 +449,11 @@ def test_error_behaviour(gpu, ckpt_root):
     ad = AudioDec(tx_device=DEV, rx_device=DEV)
     with pytest.raises(AssertionError):
         ad.load_transmitter("exp/does/not/exist.pkl")
-    with pytest.raises(native.NativeError):
-        AudioDec(tx_device="cpu", rx_device="cpu").load_transmitter(synth.write_model(ckpt_root, "vctk_sym", 1337)[1])
+    # the reference's 'cpu' defaults: mapped to the first HIP device with a warning (there is no CPU compute path)
+    native._warned_cpu = False
+    with pytest.warns(UserWarning, match="mapped to 'cuda:0'"):
+        ad_cpu = AudioDec()
+    assert ad_cpu.tx_device == "cuda:0" and ad_cpu.rx_device == "cuda:0"
     ad = load_audiodec(ckpt_root, "vctk_sym", 1337, 2, 2)
     with pytest.raises(ValueError):
         ad.tx_encoder.encode(torch.zeros(3, 1, 300, device=DEV))      # wrong stream count
@@ -476,6 +479,17 @@ def test_wire_format_matches_oracle_bit_for_bit(gpu):
         assert np.array_equal(back, idx)
     # edge: empty batch of frames
     assert wire.pack_codes(torch.zeros(8, 1, 0, dtype=torch.int64, device=gpu)).shape == (1, 0, 10)
+    # an index that is not a code of its stage: packing is asynchronous (no exception, no synchronisation inside a tick), the
+    # failure sits in the sticky device flags until the caller's next check; check=True does that check in place
+    from audiodec_amd import native
+    assert native.device_flags() == 0
+    bad = torch.from_numpy(gold_idx).to(gpu).clone()
+    bad.view(8, -1)[3, 0] = 5                                            # a stage-0 index in stage 3's row
+    wire.pack_codes(bad, 1024)
+    assert native.device_flags() == native.FLAG_BAD_CODE
+    assert native.device_flags() == 0                                    # read-and-clear
+    with pytest.raises(ValueError):
+        wire.pack_codes(bad, 1024, check=True)
 
 
 def test_packed_lookup_equals_lookup(gpu, ckpt_root):

@@ -264,3 +264,22 @@ def test_pmc_summary_keeps_only_the_marked_region(tmp_path):
     lines = out.read_text().splitlines()
     assert lines[0].startswith("# region: launches between the two")
     assert lines[2] == '"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,2,200,400,20'
+
+
+def test_bench_gpus_n_launches_its_own_ranks_or_fails_loudly():
+    """`python bench.py --gpus N` without a torchrun environment re-executes itself under torch.distributed.run with N ranks
+    (bench.self_launch); with fewer than N HIP devices visible that is an error (rc 2, a message, no JSON line) -- never a silent
+    1-rank run that reports n_gpus 1.  (The 2-rank launch itself is rehearsed on the GPU box: test_bench_two_ranks_rehearsal_on_one_gpu.)"""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ADK_BENCH_ONE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "HIP device(s) visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    # under a launcher (WORLD_SIZE set) a mismatching --gpus is refused before anything is built or timed
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
