@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <algorithm>
+#include <cstring>
 #include "../../include/audiodec_hip.h"
 
 namespace adk {
@@ -73,6 +74,10 @@ bool conv_rl16_preferred(const ConvArgs& a);
 int launch_conv_rl16(const ConvArgs& a, hipStream_t s);
 bool conv_rl16_fusable(const ConvArgs& a1, const ConvArgs& a2);      // residual unit (K7 conv -> 1x1 + residual) as one launch
 int launch_conv_rl16_fused(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s);   // ADK_ERR_STATE: not fusable for this call
+// a whole residual chain (A_0, B_0 + residual, A_1, ...) as one launch, activations resident in LDS (conv_rb16.hip)
+bool conv_rb16_fusable(const ConvArgs* c, int n);
+int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s);   // ADK_ERR_STATE: not fusable for this call
+const char* conv_rb16_name(const ConvArgs* c, int n);
 bool conv_up16_supported(const ConvArgs& a);        // streaming kernel of the last up-sampling stage (64 -> s*Cout <= 96 rows, 2 taps)
 int launch_conv_up16(const ConvArgs& a, hipStream_t s);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)

@@ -1,0 +1,525 @@
+// conv_rb16 -- a whole RESIDUAL CHAIN in one launch, activations resident in LDS (split-f16 operands on the f16 matrix cores).
+//
+// The reference runs a residual block as a Python loop over modules, every intermediate tensor going through memory:
+//   HiFiGANResidualBlock.inference  models/vocoder/modules/residual_block.py:99-105
+//       for idx: xt = convs1[idx](act(x)); xt = convs2[idx](act(xt)); x = xt + x
+//   EncoderBlock / DecoderBlock     models/autoencoder/modules/{encoder.py:76-81, decoder.py:73-78} over
+//   CausalResidualUnit.inference    models/autoencoder/modules/residual_unit.py:78-81      x + conv2(act(conv1(act(x))))
+// i.e. a chain of `units` pairs (conv A: K taps, dilation d_u; conv B: K taps or 1x1, dilation 1; + residual), each conv
+// carrying its own causal history (layers/conv_layer.py:153-156).  The per-op lowering of this repository kept that shape:
+// 2 * units launches per block (units launches with conv_rl16<FUSE>), each of which stages its input rows from HBM / L2,
+// multiplies, and stores -- 13 us of matrix-core work in a 32 us span per launch (profiles/r2_sk16_timeline.md 5-6).
+//
+// Here ONE workgroup owns `spw` streams of one group for the whole chain:
+//   * the chain input (new rows + history of conv 0) is staged ONCE into LDS, activated and split into f16 hi / lo halves
+//     (the B-operand layout of conv_rl16.hip: row = [C halfs hi][C halfs lo][16 B pad]);
+//   * every conv is the rows-in-LDS implicit GEMM of conv_rl16 (weights stream from L2 in MFMA-fragment order, two chunks
+//     ahead; B fragments are ds_read_b128 at a shifted row); its result stays in REGISTERS, gets bias / residual there,
+//     and after a barrier is written back over the same LDS rows, activated and split, as the next conv's input;
+//   * the residual x of a unit is read back from its ring at the END of the unit's second conv, by the very lane that stored it
+//     two convs earlier (same column, same channels: a lane always sees its own stores) -- 32 registers per wave would
+//     otherwise be pinned through both MFMA loops, and the kernel has none to spare at 3 waves per SIMD;
+//   * the causal history of conv k+1 (rows its input ring received in EARLIER calls) is fetched from the ring while the
+//     epilogue of conv k runs, and written in front of the new rows;
+//   * the intermediate h of a unit goes to HBM only as far as later calls need it as history: its last `keep` rows
+//     (keep = the ring's history length: 10 of 100..300 rows for the K11 blocks, none for a 1x1 second conv); unit outputs
+//     are stored in full (the next unit's residual, and the last `keep` rows are later calls' history).
+// Columns of the implicit GEMM are (stream, step) pairs packed densely (n = s * T + t), so several streams of a short
+// frame share a 32-column MFMA tile (128-channel layers: 2 streams x 25 steps per workgroup).
+// Per output element the operations and their order are exactly those of conv_rl16 (k ascending, acc0 + acc1/2048, + bias,
+// + residual): the result is BIT-IDENTICAL to the per-op path (tests/test_gpu_b256.py::test_residual_chains_are_bit_identical).
+#include "adk_common.h"
+#include <type_traits>
+#include <cstdlib>
+
+namespace adk {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kRbMaxConvs = 8;
+constexpr int kRbMaxHist = 56;           // rows of causal history a conv of the chain may need ((K-1) * dilation: 54 for K7 d9, 50 for K11 d5)
+constexpr float kRbLoScale = 2048.f, kRbLoInv = 1.f / 2048.f;
+
+struct RbNode {                          // a tensor of the chain: where its rows live in HBM (a state ring)
+    float* base; int rows, ch, cursor, choff, gstride;      // row of step t of stream b: base + (b * rows + (cursor + t) mod rows) * ch + choff + g * gstride
+    int keep;                            // rows of history later calls read from this ring (intermediate nodes only)
+};
+struct RbConv { const float* wfrag; const float* bias; int dil, hist, ksteps; unsigned w_bytes; };
+struct RbArgs {
+    RbNode node[kRbMaxConvs + 1];        // node k = input of conv k, node k+1 = its output; node 2u = residual of conv 2u+1
+    RbConv conv[kRbMaxConvs];
+    int n_convs, batch, t, groups;
+    int spw;                             // streams per workgroup
+    int hm;                              // history rows in front of a stream's new rows in LDS (max over convs)
+    int rps;                             // LDS rows per stream = hm + t
+    int n_tiles;                         // 32-column tiles of a full workgroup (ceil(spw * t / 32))
+    float slope; int* err;
+};
+
+template <int ACT>
+__device__ __forceinline__ float rb_act(float x, float slope) {
+    if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
+    if (ACT == ADK_ACT_LEAKY) return x > 0.f ? x : x * slope;
+    return x;
+}
+
+__device__ __forceinline__ f16x8 rb_as_f16x8(const u32x4s& v) {
+    union { u32x4s u; f16x8 h; } c; c.u = v; return c.h;
+}
+
+// 8 consecutive channels of one row: activation, split into hi / lo halves, into the row's LDS slots
+template <int C, int ACT>
+__device__ __forceinline__ void rb_put8(unsigned char* dst, const float4& u, const float4& v, float slope) {
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float y = rb_act<ACT>(x[j], slope);
+        const _Float16 h = (_Float16)y;
+        hi[j] = h;
+        lo[j] = (_Float16)((y - (float)h) * kRbLoScale);
+    }
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 2 * C) = lo;
+}
+
+// One conv of the chain for this wave's work item (m-tile, two n-tiles): the MFMA sequence of conv_rl16_kernel, straight-line
+// (a wave whose second n-tile lies past the last column computes it on clamped addresses and never stores it).
+// x0 / x1: this lane's B-fragment address for tap 0, chunk 0 of the two n-tiles; dil_rs = dilation * row stride.
+template <int C, int TAPS, int PF>
+__device__ __forceinline__ void rb_mfma(const unsigned char* x0, const unsigned char* x1, int dil_rs,
+                                        const __amdgpu_buffer_rsrc_t rsrc_w, unsigned lane16, unsigned wbase,
+                                        u32x4s (&ah)[PF + 1], u32x4s (&al)[PF + 1],
+                                        f32x16& m0, f32x16& m1, f32x16& c0, f32x16& c1) {
+    constexpr int CH = C / 16, STEPS = TAPS * CH;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        if (s + PF < STEPS) {
+            ah[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wbase + (unsigned)(s + PF) * 2048u, 0);
+            al[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wbase + (unsigned)(s + PF) * 2048u, 0);
+        }
+        const int tap = s / CH, ch = s - tap * CH;
+        const int off = tap * dil_rs + 32 * ch;
+        const f16x8 Ah = rb_as_f16x8(ah[s % (PF + 1)]), Al = rb_as_f16x8(al[s % (PF + 1)]);
+        const f16x8 b0h = *reinterpret_cast<const f16x8*>(x0 + off);
+        const f16x8 b0l = *reinterpret_cast<const f16x8*>(x0 + off + 2 * C);
+        const f16x8 b1h = *reinterpret_cast<const f16x8*>(x1 + off);
+        const f16x8 b1l = *reinterpret_cast<const f16x8*>(x1 + off + 2 * C);
+        m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1h, m1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1l, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b1h, c1, 0, 0, 0);
+    }
+}
+
+// NW waves per workgroup, each with at most ONE work item (m-tile of 32 output channels, pair of 32-column tiles).
+// SMAX = most streams a workgroup takes (sizes the register staging of the history rows).
+template <int C, int ACT, int TA, int TB, int NW, int SMAX>
+__global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(RbArgs r) {
+    constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
+    constexpr int C8 = C / 8;
+    constexpr int MT = C / 32;
+    constexpr int NT = 64 * NW;
+    constexpr int PF = 2;
+    constexpr bool BIAS_LDS = C < 128;                 // bias of every conv staged in LDS (the 128-channel variant has no LDS to spare, but registers)
+    constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    const int g = blockIdx.x % r.groups;
+    const int b0 = (blockIdx.x / r.groups) * r.spw;
+    const int scur = min(r.spw, r.batch - b0);
+    const int T = r.t;
+    const int ncols = scur * T;
+    const int n_tiles = (ncols + 31) >> 5;
+    float* bias_lds = reinterpret_cast<float*>(xs + (size_t)r.spw * r.rps * RS);      // [n_convs][C]
+
+    // ---- this wave's work item; this lane's two GEMM columns.  Everything below is straight-line for every wave: a wave
+    // without an item (fewer columns than a full workgroup) and columns past the end compute on clamped addresses and are
+    // masked where something is STORED (valid[]) -- no divergent control flow around the MFMA loops, no values kept alive
+    // across them by a branch ----
+    const int n_pairs = (r.n_tiles + 1) >> 1;
+    const int mt_w = wave / n_pairs;
+    const int nt0 = 2 * (wave - mt_w * n_pairs);
+    const bool has_item = mt_w < MT && nt0 < n_tiles;
+    const int mt = min(mt_w, MT - 1);
+    bool valid[2]; int sj[2], tj[2], lrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = (nt0 + j) * 32 + l31;
+        valid[j] = has_item && n < ncols;
+        const int nc = min(n, ncols - 1);
+        sj[j] = nc / T; tj[j] = nc - sj[j] * T;
+        lrow[j] = sj[j] * r.rps + r.hm + tj[j];
+    }
+
+    // ---- first weight fragments of conv 0: issued before anything else (their L2 round trip overlaps the staging) ----
+    u32x4s ah[PF + 1], al[PF + 1];
+    auto preload = [&](const RbConv& cv, int steps) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
+        const unsigned wb = (unsigned)((g * MT + mt) * cv.ksteps) * 2048u;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            if (s < steps) {
+                ah[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_, lane16, wb + (unsigned)s * 2048u, 0);
+                al[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_, lane16 + 1024u, wb + (unsigned)s * 2048u, 0);
+            }
+        }
+    };
+    preload(r.conv[0], TA * (C / 16));
+
+    // ---- stage the chain input: rows [-hist_0, T) of every stream, activated and split ----
+    {
+        const RbNode& nd = r.node[0];
+        const int h0 = r.conv[0].hist;
+        const int per = (h0 + T) * C8;                  // 8-channel pieces per stream
+        const int total = scur * per;
+        for (int i0 = tid; i0 < total; i0 += 2 * NT) {
+            float4 u[2], v[2]; int dst[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = i0 + k * NT;
+                dst[k] = -1;
+                if (i < total) {
+                    const int s = i / per, rem = i - s * per;
+                    const int rr = rem / C8, c8 = rem - rr * C8;
+                    int row = nd.cursor - h0 + rr;
+                    if (row < 0) row += nd.rows;
+                    if (row >= nd.rows) row -= nd.rows;
+                    const float4* p = reinterpret_cast<const float4*>(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 8 * c8);
+                    u[k] = p[0]; v[k] = p[1];
+                    dst[k] = (s * r.rps + r.hm - h0 + rr) * RS + 16 * c8;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (dst[k] >= 0) rb_put8<C, ACT>(xs + dst[k], u[k], v[k], r.slope);
+        }
+        if constexpr (BIAS_LDS) {
+            for (int i = tid; i < r.n_convs * C; i += NT) {
+                const int k = i / C, c = i - k * C;
+                bias_lds[i] = r.conv[k].bias ? r.conv[k].bias[g * C + c] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    bool bad = false;
+
+    // history rows [-hist, 0) of node `k` (all streams of this workgroup): issue the loads / convert and write them in front of the new rows
+    auto hist_issue = [&](int k, float4 (&hu)[NHP], float4 (&hv)[NHP]) __attribute__((always_inline)) {
+        const RbNode& nd = r.node[k];
+        const int hk = r.conv[k].hist;
+        const int per = hk * C8, total = scur * per;
+#pragma unroll
+        for (int q = 0; q < NHP; ++q) {
+            const int i = tid + q * NT;
+            hu[q] = hv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total) {
+                const int s = i / per, rem = i - s * per;
+                const int rr = rem / C8, c8 = rem - rr * C8;
+                int row = nd.cursor - hk + rr;
+                if (row < 0) row += nd.rows;
+                const float4* p = reinterpret_cast<const float4*>(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 8 * c8);
+                hu[q] = p[0]; hv[q] = p[1];
+            }
+        }
+    };
+    auto hist_commit = [&](int k, const float4 (&hu)[NHP], const float4 (&hv)[NHP]) __attribute__((always_inline)) {
+        const int hk = r.conv[k].hist;
+        const int per = hk * C8, total = scur * per;
+#pragma unroll
+        for (int q = 0; q < NHP; ++q) {
+            const int i = tid + q * NT;
+            if (i < total) {
+                const int s = i / per, rem = i - s * per;
+                const int rr = rem / C8, c8 = rem - rr * C8;
+                rb_put8<C, ACT>(xs + (s * r.rps + r.hm - hk + rr) * RS + 16 * c8, hu[q], hv[q], r.slope);
+            }
+        }
+    };
+    // this wave's 16 bias values per lane: from LDS in the epilogue, or (128-channel variant) fetched under the MFMAs
+    auto bias_issue = [&](int k, float4 (&breg)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            breg[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (!BIAS_LDS) {
+                if (r.conv[k].bias) breg[qd] = *reinterpret_cast<const float4*>(r.conv[k].bias + g * C + mt * 32 + 8 * qd + 4 * lh);
+            }
+        }
+    };
+    // h = acc0 + acc1/2048 (+ bias), in the order of conv_rl16's epilogue
+    auto finish = [&](int k, bool vld, const f32x16& am, const f32x16& ac, const float4 (&breg)[4], float (&h)[16]) __attribute__((always_inline)) {
+        const bool hb = r.conv[k].bias != nullptr;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float4 bb = breg[qd];
+            if constexpr (BIAS_LDS) bb = *reinterpret_cast<const float4*>(bias_lds + k * C + mt * 32 + 8 * qd + 4 * lh);
+            float v0 = fmaf(ac[4 * qd], kRbLoInv, am[4 * qd]), v1 = fmaf(ac[4 * qd + 1], kRbLoInv, am[4 * qd + 1]);
+            float v2 = fmaf(ac[4 * qd + 2], kRbLoInv, am[4 * qd + 2]), v3 = fmaf(ac[4 * qd + 3], kRbLoInv, am[4 * qd + 3]);
+            bad |= vld & (!(fabsf(v0) <= 3.0e38f) | !(fabsf(v1) <= 3.0e38f) | !(fabsf(v2) <= 3.0e38f) | !(fabsf(v3) <= 3.0e38f));
+            if (hb) { v0 += bb.x; v1 += bb.y; v2 += bb.z; v3 += bb.w; }
+            h[4 * qd] = v0; h[4 * qd + 1] = v1; h[4 * qd + 2] = v2; h[4 * qd + 3] = v3;
+        }
+    };
+    // rows of node k that later calls need (or all of them): straight from registers, raw f32
+    auto ring_store = [&](int k, int j, const float (&h)[16], bool all) __attribute__((always_inline)) {
+        const RbNode& nd = r.node[k];
+        if (!valid[j] || !(all || tj[j] >= T - nd.keep)) return;
+        int row = nd.cursor + tj[j];
+        if (row >= nd.rows) row -= nd.rows;
+        float* p = nd.base + ((size_t)(b0 + sj[j]) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + mt * 32 + 4 * lh;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(p + 8 * qd) = make_float4(h[4 * qd], h[4 * qd + 1], h[4 * qd + 2], h[4 * qd + 3]);
+    };
+    // the residual of a unit (node k) at this lane's column j: the chain input, or what this very lane stored at the end of the previous unit
+    auto res_load = [&](int k, int j, float4 (&rr)[4]) __attribute__((always_inline)) {
+        const RbNode& nd = r.node[k];
+        int row = nd.cursor + tj[j];
+        if (row >= nd.rows) row -= nd.rows;
+        const float* p = nd.base + ((size_t)(b0 + sj[j]) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + mt * 32 + 4 * lh;
+        // `nt` loads are served by L2, never by this CU's vector L1: a line of that L1 may have been filled, BEFORE this lane's
+        // store, by the history fetch of the neighbouring row (rings are only 16-byte aligned, a 128-byte line can span two rows)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 8 * qd));     // (a clamped column re-reads a valid one)
+            rr[qd] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    // act(h), split, over this lane's LDS row: the next conv's B operand
+    auto lds_put = [&](int j, const float (&h)[16]) __attribute__((always_inline)) {
+        if (!valid[j]) return;
+        unsigned char* row = xs + lrow[j] * RS;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int ml = mt * 32 + 8 * qd + 4 * lh;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = rb_act<ACT>(h[4 * qd + e], r.slope);
+                const _Float16 hh = (_Float16)y;
+                hi[e] = hh;
+                lo[e] = (_Float16)((y - (float)hh) * kRbLoScale);
+            }
+            *reinterpret_cast<f16x4*>(row + 2 * ml) = hi;
+            *reinterpret_cast<f16x4*>(row + 2 * C + 2 * ml) = lo;
+        }
+    };
+
+    const int units = r.n_convs >> 1;
+#pragma unroll 1
+    for (int u = 0; u < units; ++u) {
+        // ================= conv A: node 2u -> node 2u+1 =================
+        {
+            const int k = 2 * u;
+            const RbConv cv = r.conv[k];
+            f32x16 m0, m1, c0, c1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
+            float4 breg[4];
+            bias_issue(k, breg);
+            const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
+            const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
+            const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
+            rb_mfma<C, TA, PF>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps) * 2048u, ah, al, m0, m1, c0, c1);
+            preload(r.conv[k + 1], TB * (C / 16));              // the next conv's first fragments arrive under the epilogue
+            float4 hu[NHP], hv[NHP];                            // history rows of the next conv's input, in flight during the epilogue
+            hist_issue(k + 1, hu, hv);
+            float h0[16], h1[16];
+            finish(k, valid[0], m0, c0, breg, h0); ring_store(k + 1, 0, h0, false);
+            finish(k, valid[1], m1, c1, breg, h1); ring_store(k + 1, 1, h1, false);
+            __syncthreads();                            // every wave is done reading the rows of conv A's input
+            lds_put(0, h0); lds_put(1, h1);
+            hist_commit(k + 1, hu, hv);
+            __syncthreads();
+        }
+        // ================= conv B: node 2u+1 -> node 2u+2, + residual (node 2u) =================
+        {
+            const int k = 2 * u + 1;
+            const RbConv cv = r.conv[k];
+            const bool last = u + 1 == units;
+            const int kn = last ? k : k + 1;                    // (the last conv prefetches its own data again: harmless, keeps the code straight-line)
+            f32x16 m0, m1, c0, c1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
+            float4 breg[4];
+            bias_issue(k, breg);
+            const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
+            const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
+            const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
+            rb_mfma<C, TB, PF>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps) * 2048u, ah, al, m0, m1, c0, c1);
+            preload(r.conv[kn], TA * (C / 16));
+            float4 hu[NHP], hv[NHP];
+            hist_issue(kn, hu, hv);
+            float4 r0[4], r1[4];
+            res_load(k - 1, 0, r0); res_load(k - 1, 1, r1);
+            float h0[16], h1[16];
+            finish(k, valid[0], m0, c0, breg, h0);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { h0[4 * qd] += r0[qd].x; h0[4 * qd + 1] += r0[qd].y; h0[4 * qd + 2] += r0[qd].z; h0[4 * qd + 3] += r0[qd].w; }
+            ring_store(k + 1, 0, h0, true);
+            finish(k, valid[1], m1, c1, breg, h1);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { h1[4 * qd] += r1[qd].x; h1[4 * qd + 1] += r1[qd].y; h1[4 * qd + 2] += r1[qd].z; h1[4 * qd + 3] += r1[qd].w; }
+            ring_store(k + 1, 1, h1, true);
+            if (!last) {
+                __syncthreads();
+                lds_put(0, h0); lds_put(1, h1);
+                hist_commit(kn, hu, hv);
+                __syncthreads();
+            }
+        }
+    }
+    if (bad) atomicOr(r.err, 8);
+}
+
+struct RbPlan { int C, ta, tb, nw, spw, n_tiles, hm, rps; size_t lds; long long blocks; };
+
+int rb_streams_per_wg(int C, int batch, int t) {
+    static int env = -1;                                // tuning: ADK_RB16_SPW (streams per workgroup of the 128-channel chains)
+    if (env < 0) { const char* e = getenv("ADK_RB16_SPW"); env = e ? atoi(e) : 0; }
+    int s = (C == 128) ? 2 : 1;
+    if (env > 0 && C == 128) s = std::min(env, 2);
+    while (s > 1 && (s > batch || s * t > 64)) --s;
+    return s;
+}
+
+// Geometry of the launch, or false when the chain does not fit this kernel for this call.
+bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
+    const ConvArgs& a0 = c[0];
+    pl.C = a0.cin_g; pl.ta = a0.taps; pl.tb = c[1].taps;
+    const int T = a0.t_out;
+    pl.spw = rb_streams_per_wg(pl.C, a0.batch, T);
+    pl.n_tiles = (pl.spw * T + 31) / 32;
+    const int items = (pl.C / 32) * ((pl.n_tiles + 1) / 2);
+    if (items > 5) return false;
+    pl.nw = items == 5 ? 5 : 4;
+    pl.hm = 0;
+    for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
+    if (pl.hm > kRbMaxHist) return false;
+    pl.rps = pl.hm + T;
+    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (pl.C < 128 ? (size_t)n * pl.C * 4 : 0);
+    if (pl.lds > 160 * 1024) return false;
+    pl.blocks = (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups;
+    return pl.blocks <= 0x7fffffffLL;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// c[0..n): the convs of the chain in launch order (A_0, B_0, A_1, B_1, ...), as op_conv_args built them for this call.
+bool conv_rb16_fusable(const ConvArgs* c, int n) {
+    if (n < 2 || n > kRbMaxConvs || (n & 1)) return false;
+    const ConvArgs& a0 = c[0];
+    const int C = a0.cin_g;
+    if (C != 32 && C != 64 && C != 128) return false;
+    if (a0.act_in != ADK_ACT_ELU && a0.act_in != ADK_ACT_LEAKY) return false;
+    const int ta = a0.taps, tb = c[1].taps;
+    if (!((ta == 11 && tb == 11) || (ta == 7 && tb == 7) || (ta == 3 && tb == 3) || (ta == 7 && tb == 1))) return false;
+    if (a0.act_in == ADK_ACT_ELU && !(ta == 7 && tb == 1)) return false;          // instantiated: ELU residual units, LeakyReLU residual blocks
+    if (a0.act_in == ADK_ACT_LEAKY && tb == 1) return false;
+    if (a0.t_out < 1 || a0.batch < 1) return false;
+    for (int k = 0; k < n; ++k) {
+        const ConvArgs& a = c[k];
+        const bool isB = k & 1;
+        if (!a.wfrag || !aligned16(a.wfrag) || (a.bias && !aligned16(a.bias))) return false;
+        if (a.cin_g != C || a.cout_g != C || a.groups != a0.groups || a.stride != 1 || a.up != 1 || a.cout_real != a.groups * C) return false;
+        if (a.taps != (isB ? tb : ta) || a.dilation < 1) return false;
+        if (a.act_in != a0.act_in || a.slope != a0.slope || a.act_out != ADK_ACT_NONE) return false;
+        if (a.batch != a0.batch || a.t_out != a0.t_out) return false;
+        if ((a.in_ch % 4) || (a.in_choff % 4) || (a.in_gstride % 4) || (a.out_ch % 4) || (a.out_choff % 4) || !aligned16(a.in) || !aligned16(a.out)) return false;
+        if (a.in_rows < a.t_out + (a.taps - 1) * a.dilation || a.out_rows < a.t_out) return false;
+        if (k > 0) {                                    // reads exactly what the previous conv wrote, group by group
+            const ConvArgs& p = c[k - 1];
+            if (a.in != p.out || a.in_rows != p.out_rows || a.in_ch != p.out_ch || a.in_choff != p.out_choff || a.in_gstride != C) return false;
+            if ((a.in_row0 + (a.taps - 1) * a.dilation) % a.in_rows != p.out_cursor) return false;
+        }
+        if (!isB) {
+            if (a.res) return false;
+        } else {                                        // residual = the input of the unit's first conv, at the new rows
+            const ConvArgs& f = c[k - 1];
+            if (!a.res || a.res != f.in || a.res_rows != f.in_rows || a.res_ch != f.in_ch || a.res_choff != f.in_choff || a.res_gstride != f.in_gstride) return false;
+            if (a.res_cursor != (f.in_row0 + (f.taps - 1) * f.dilation) % f.in_rows) return false;
+        }
+    }
+    RbPlan pl;
+    return rb_plan(c, n, pl);
+}
+
+namespace {
+template <int C, int ACT, int TA, int TB, int NW, int SMAX>
+int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
+    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NW, SMAX>;
+    if (pl.lds > 64 * 1024) {
+        static bool attr_set_dev[kMaxDevices] = {};     // function attributes are per device
+        bool& attr_set = attr_set_dev[current_device()];
+        if (!attr_set) {
+            ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(64 * NW), pl.lds, s, r);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
+template <int C, int NW, int SMAX>
+int rb_by_taps(const RbArgs& r, const RbPlan& pl, int act, hipStream_t s) {
+    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NW, SMAX>(r, pl, s);
+    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NW, SMAX>(r, pl, s);
+    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NW, SMAX>(r, pl, s);
+    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NW, SMAX>(r, pl, s);
+}
+}  // namespace
+
+// keep[k]: rows of history the ring behind node k+1 (the output of conv k) must hold for later calls (its ring's `hist`), k < n-1
+int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
+    if (!conv_rb16_fusable(c, n)) return ADK_ERR_STATE;
+    RbPlan pl;
+    if (!rb_plan(c, n, pl)) return ADK_ERR_STATE;
+    if (c[0].n_total == 0) return ADK_OK;
+    RbArgs r;
+    memset(&r, 0, sizeof(r));
+    const ConvArgs& a0 = c[0];
+    r.node[0].base = const_cast<float*>(a0.in); r.node[0].rows = a0.in_rows; r.node[0].ch = a0.in_ch;
+    r.node[0].cursor = (a0.in_row0 + (a0.taps - 1) * a0.dilation) % a0.in_rows;
+    r.node[0].choff = a0.in_choff; r.node[0].gstride = a0.in_gstride; r.node[0].keep = 0;
+    for (int k = 0; k < n; ++k) {
+        const ConvArgs& a = c[k];
+        RbNode& nd = r.node[k + 1];
+        nd.base = a.out; nd.rows = a.out_rows; nd.ch = a.out_ch; nd.cursor = a.out_cursor; nd.choff = a.out_choff; nd.gstride = a.cout_g;
+        nd.keep = k + 1 < n ? std::max(keep[k], (c[k + 1].taps - 1) * c[k + 1].dilation) : 0;
+        RbConv& cv = r.conv[k];
+        cv.wfrag = a.wfrag; cv.bias = a.bias; cv.dil = a.dilation; cv.hist = (a.taps - 1) * a.dilation;
+        cv.ksteps = (a.ktot + 63) / 64 * 4;
+        cv.w_bytes = (unsigned)((unsigned long long)a.groups * (a.cout_g / 32) * cv.ksteps * 2048ull);
+    }
+    r.n_convs = n; r.batch = a0.batch; r.t = a0.t_out; r.groups = a0.groups;
+    r.spw = pl.spw; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
+    r.slope = a0.slope; r.err = flags_word();
+    const int act = a0.act_in;
+    if (pl.C == 32) return pl.nw == 5 ? rb_by_taps<32, 5, 1>(r, pl, act, s) : rb_by_taps<32, 4, 1>(r, pl, act, s);
+    if (pl.C == 64) return rb_by_taps<64, 4, 1>(r, pl, act, s);
+    return rb_by_taps<128, 4, 2>(r, pl, act, s);
+}
+
+const char* conv_rb16_name(const ConvArgs* c, int n) {
+    (void)n;
+    return c[0].cin_g == 32 ? "conv_rb16<32>" : (c[0].cin_g == 64 ? "conv_rb16<64>" : "conv_rb16<128>");
+}
+
+}  // namespace adk

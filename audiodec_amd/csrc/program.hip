@@ -72,6 +72,7 @@ static int ensure_workspace(Workspace& w) {
 
 static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
 static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
+static int g_use_chain = -1;    // ADK_CHAIN=0: residual chains run op by op (A/B against the per-op kernels)
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
@@ -79,6 +80,7 @@ static bool is_split16(int impl) {
 static void read_env() {
     if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
     if (g_use_up < 0) { const char* e = getenv("ADK_CONV_UP16"); g_use_up = e ? atoi(e) : 1; }
+    if (g_use_chain < 0) { const char* e = getenv("ADK_CHAIN"); g_use_chain = e ? atoi(e) : 1; }
 }
 
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
@@ -379,14 +381,40 @@ static bool op_pair_fusable(adk_program* p, int i, int frames, void* const* ext,
     return conv_rl16_fusable(a1, a2);
 }
 
-// one op of the launch sequence on stream s; *consumed = 2 when the op was launched together with its successor
-static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream_t s, int* consumed = nullptr) {
+// Can ops [i, i + n) (a residual chain, adk_op_desc.chain) run as one launch for a `frames`-hop step?  Fills c[] / keep[].
+constexpr int kMaxChain = 8;
+static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext, ConvArgs* c, int* keep) {
+    read_env();
+    const int n = p->ops[i].chain;
+    if (!g_use_chain || !g_use_rl || n < 2 || n > kMaxChain || i + n > (int)p->ops.size()) return false;
+    for (int k = 0; k < n; ++k) {
+        const adk_op_desc& o = p->ops[i + k];
+        if (o.kind != ADK_OP_CONV || o.impl != ADK_IMPL_SPLIT16) return false;
+        if (k > 0 && o.chain > 1) return false;
+        if (k + 1 < n && (p->rings[o.out_ring].external >= 0 || p->ops[i + k + 1].in_ring != o.out_ring)) return false;
+        if (op_conv_args(p, i + k, frames, ext, c[k]) != ADK_OK) return false;
+        keep[k] = p->rings[o.out_ring].hist;
+    }
+    return conv_rb16_fusable(c, n);
+}
+
+// one op of the launch sequence on stream s; *consumed = how many ops of the sequence this launch covered (a residual unit or a
+// whole residual chain run as one kernel), at most max_consume
+static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream_t s, int max_consume = 1, int* consumed = nullptr) {
     const adk_op_desc& o = p->ops[i];
     int rc = ADK_OK;
     if (consumed) *consumed = 1;
     if (o.kind == ADK_OP_CONV) {
         ConvArgs a, a2;
-        if (consumed && o.fuse_next && op_pair_fusable(p, i, frames, ext, a, a2)) {
+        if (consumed && o.chain >= 2 && o.chain <= max_consume) {
+            ConvArgs c[kMaxChain]; int keep[kMaxChain];
+            if (op_chain_fusable(p, i, frames, ext, c, keep)) {
+                rc = launch_conv_rb16(c, o.chain, keep, s);
+                if (rc == ADK_OK) { *consumed = o.chain; return ADK_OK; }
+                if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (chain): " + g_err; return rc; }
+            }
+        }
+        if (consumed && max_consume >= 2 && o.fuse_next && op_pair_fusable(p, i, frames, ext, a, a2)) {
             rc = launch_conv_rl16_fused(a, a2, s);
             if (rc == ADK_OK) { *consumed = 2; return ADK_OK; }
             if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (fused): " + g_err; return rc; }
@@ -518,7 +546,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
                 hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(p->ws.ptr) + p->ws.flags_offset, 0, p->ws.bytes - p->ws.flags_offset, s);
                 if (e != hipSuccess) rc = fail(ADK_ERR_HIP, std::string("graph capture: memset: ") + hipGetErrorString(e));
                 // (no fusion across the end of the captured range: op g_hi touches a caller buffer whose pointer would be baked into the graph)
-                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK;) { int used = 1; rc = run_op(p, k, frames, ext, s, k + 1 < p->g_hi ? &used : nullptr); k += used; }
+                for (int k = p->g_lo; k < p->g_hi && rc == ADK_OK;) { int used = 1; rc = run_op(p, k, frames, ext, s, p->g_hi - k, &used); k += used; }
                 e = hipStreamEndCapture(s, &g);
                 if (rc != ADK_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
                 if (e != hipSuccess || !g) return fail(ADK_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -535,10 +563,11 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
             continue;
         }
         int used = 1;
-        int rc = run_op(p, i, frames, ext, s, (i + 1 < n_ops && !(replay && i + 1 == p->g_lo)) ? &used : nullptr);
+        // a launch may cover the ops that follow (residual unit / chain), but never reach into a range that is replayed as a graph
+        int rc = run_op(p, i, frames, ext, s, (replay && i < p->g_lo ? p->g_lo : n_ops) - i, &used);
         if (rc != ADK_OK) return rc;
         if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[i + 1], s));
-        if (used == 2) {                      // the successor ran inside the same launch
+        for (; used > 1; --used) {            // the successors ran inside the same launch
             ++i;
             if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[i + 1], s));
         }
@@ -572,7 +601,12 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         if (rc != ADK_OK) return rc;
         name = conv_kernel_name(a, o.impl);
         ConvArgs f1, f2;
-        if (o.fuse_next && op_pair_fusable(p, op, frames, ext, f1, f2)) name = f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>";
+        ConvArgs c[kMaxChain]; int keep[kMaxChain];
+        int head = -1;                              // the chain this op belongs to, when that chain runs as one launch
+        for (int h = op; h >= 0 && h > op - kMaxChain; --h)
+            if (p->ops[h].kind == ADK_OP_CONV && p->ops[h].chain >= 2 && h + p->ops[h].chain > op) { head = h; break; }
+        if (head >= 0 && op_chain_fusable(p, head, frames, ext, c, keep)) name = head == op ? conv_rb16_name(c, p->ops[head].chain) : "(fused into the previous op)";
+        else if (o.fuse_next && op_pair_fusable(p, op, frames, ext, f1, f2)) name = f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>";
         else if (op > 0 && p->ops[op - 1].fuse_next && op_pair_fusable(p, op - 1, frames, ext, f1, f2)) name = "(fused into the previous op)";
     }
     snprintf(buf, n, "%s", name.c_str());

@@ -110,6 +110,7 @@ def mfma_eligible(cin_g, cout_g, groups):
 
 
 FUSE_RES_UNITS = os.environ.get("ADK_FUSE", "1") != "0"      # ADK_FUSE=0: every residual unit as two launches (A/B, cross-checks)
+FUSE_CHAINS = os.environ.get("ADK_CHAIN", "1") != "0"        # ADK_CHAIN=0: residual chains (a block's three units) op by op, not as one launch
 
 
 class Blob:
@@ -246,6 +247,7 @@ class Builder:
         op.ext_src = -1
         op.impl = impl
         op.fuse_next = 1 if fuse_next else 0
+        op.chain = 0
         self.ops.append(op)
         self.op_names.append(name)
         self.flops_per_frame += 2 * packed.numel() * rate_out
@@ -266,13 +268,17 @@ def _act_of(params, default="ELU"):
 
 def _res_units(b, pre, x_ring, c, rate, act, slope, out_ring_of_last):
     """3x CausalResidualUnit.inference; returns the ring holding the block output."""
+    first = None
     for j in range(3):
         h = b.scratch_ring(c, rate, "h")
         # h is read by conv2 only: the runner may run the unit as one kernel (adk_op_desc.fuse_next)
-        b.conv(f"{pre}.res_units.{j}.conv1", x_ring, h, act, slope, fuse_next=FUSE_RES_UNITS)
+        op = b.conv(f"{pre}.res_units.{j}.conv1", x_ring, h, act, slope, fuse_next=FUSE_RES_UNITS)
+        first = first or op
         nxt = out_ring_of_last if j == 2 else b.ring(c, 0, rate)
         b.conv(f"{pre}.res_units.{j}.conv2", h, nxt, act, slope, res_ring=x_ring)
         x_ring = nxt
+    # the three units read / write rings nobody else touches in between: the runner may run all six convs as one launch
+    first.chain = 6 if FUSE_CHAINS else 0
     return x_ring
 
 
@@ -390,10 +396,13 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
             # MultiGroupConv1d.inference (multi_fusion.py:133-141): x.repeat(1, groups, 1) is never
             # materialised -- the first conv and the first residual read the same C channels per group
             x, gs_in, gs_res = x0, 0, 0
-            for j in range(len(p["resblock_dilations"][0])):
+            n_units = len(p["resblock_dilations"][0])
+            for j in range(n_units):
                 if addl:
                     xt = b.ring(c * groups, 0, rate)
-                    b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
+                    op = b.conv(f"blocks.{i}.convs1.{j}", x, xt, act, slope, in_group_stride=gs_in)
+                    if j == 0 and FUSE_CHAINS and 2 * n_units <= 8:
+                        op.chain = 2 * n_units                   # HiFiGANResidualBlock.inference as one launch (residual_block.py:99-105)
                     nx = b.ring(c * groups, 0, rate)
                     b.conv(f"blocks.{i}.convs2.{j}", xt, nx, act, slope, res_ring=x, res_group_stride=gs_res)
                 else:
@@ -409,7 +418,9 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
                 for j in range(len(dil)):
                     if addl:
                         xt = b.ring(c, 0, rate)
-                        b.conv(f"blocks.{i}.blocks.{bi}.convs1.{j}", x, xt, act, slope)
+                        op = b.conv(f"blocks.{i}.blocks.{bi}.convs1.{j}", x, xt, act, slope)
+                        if j == 0 and FUSE_CHAINS and 2 * len(dil) <= 8:
+                            op.chain = 2 * len(dil)
                         nx = b.ring(c, 0, rate)
                         b.conv(f"blocks.{i}.blocks.{bi}.convs2.{j}", xt, nx, act, slope, res_ring=x)
                     else:

@@ -179,15 +179,45 @@ def pmc_traffic(dom, split16):
     return round(num / den) if den else None
 
 
-def mean_launch_bytes(rows, dom):
+FUSED = "(fused into the previous op)"
+
+
+def launches_of(rows, streams, fps=1):
+    """Per-op rows -> per-LAUNCH records: an op the runner folded into its predecessor's launch (a residual unit or a whole
+    residual chain run as one kernel) adds its flops and its event time to that launch.  Algorithmic bytes of a fused launch:
+    chain input (new rows + history) + every conv's weights + the history rows the later convs read from / leave in their state
+    rings + the chain output, once each -- what no implementation of the streaming recurrence can avoid moving."""
+    out = []
+    for r in rows:
+        if r["kernel"] == FUSED and out and out[-1]["prog"] == r["prog"]:
+            L = out[-1]
+            L["ms"] += r["ms"]; L["flops"] += r["flops"]; L["ops"].append(r)
+            continue
+        out.append(dict(prog=r["prog"], name=r["name"], kernel=r["kernel"], ms=r["ms"], flops=r["flops"], bytes=r["bytes"], ops=[r], op=r["op"]))
+    for L in out:
+        if len(L["ops"]) > 1:
+            ops = [q["op"] for q in L["ops"]]
+            c0 = ops[0].conv
+            t = ops[0].rate_out * fps
+            m = c0.groups * c0.cout_g
+            b = streams * (t + c0.hist) * c0.cin_g * (c0.groups if c0.in_group_stride else 1)             # chain input
+            b += sum(o.conv.groups * o.conv.cout_g * o.conv.taps * o.conv.cin_g for o in ops)             # weights
+            b += sum(2 * streams * min(o.conv.hist, 10 ** 9) * m for o in ops[1:])                         # state rows read + written back
+            b += streams * t * m                                                                           # chain output
+            L["bytes"] = 4.0 * b
+    return out
+
+
+def mean_launch_bytes(launches, dom):
     """Mean compulsory bytes per launch over the launches of kernel `dom` in one step (the launches pmc_traffic averages over)."""
-    sel = [r["bytes"] for r in rows if r["kernel"] == dom and r["op"].kind == 0]
+    sel = [L["bytes"] for L in launches if L["kernel"] == dom and L["op"].kind == 0]
     return round(sum(sel) / len(sel)) if sel else None
 
 
 def roofline_from(rows, streams, fps=1, split16=False):
+    launches = launches_of(rows, streams, fps)
     by = {}
-    for r in rows:
+    for r in launches:
         d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
         d["ms"] += r["ms"]; d["flops"] += r["flops"]; d["launches"] += 1; d["bytes"] += r.get("bytes", 0.0)
     dom = max(by, key=lambda k: by[k]["ms"])
@@ -198,14 +228,15 @@ def roofline_from(rows, streams, fps=1, split16=False):
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom, split16),
-            "algorithmic_bytes_per_launch": mean_launch_bytes(rows, dom),
+            "algorithmic_bytes_per_launch": mean_launch_bytes(launches, dom),
             "traffic_note": "both are means per launch over all launches of this kernel in the timed steps: traffic = FETCH_SIZE x2 + "
                             f"WRITE_SIZE from the committed PMC passes over this bench (profiles/{PMC_TRAFFIC_FILE}, captured at commit "
                             f"{PMC_TRAFFIC_COMMIT} with {PMC_TRAFFIC_SCRIPT}, steady-state launches picked out by --pmc-markers; PMC counters cannot "
                             "be read from inside the bench process), not collected live; algorithmic = input rows incl. history + weights + "
-                            "outputs (+ residual), once each",
+                            "outputs (+ residual / state rows), once each",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-            "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3)}
+            "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3),
+            "launches_per_step_all_kernels": len(launches)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
     ct = [r for r in rows if r["name"] == "upsamples.3"]
     roof_ct = None

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 8
+#define ADK_ABI_VERSION 9
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -230,6 +230,12 @@ typedef struct {
     int32_t fuse_next;                   /* 1: this conv's output ring is read only by the NEXT op, the 1x1 conv + residual of the same
                                             residual unit (residual_unit.py:78-81): the runner may launch both as one kernel
                                             (split-f16 rows-in-LDS kernel; the intermediate then never goes to memory) */
+    int32_t chain;                       /* n >= 2: ops [this, this + n) are a residual chain -- units of (conv A; conv B + residual of A's
+                                            input), each op reading the ring its predecessor writes, every intermediate ring read by nobody
+                                            else (HiFiGANResidualBlock.inference, residual_block.py:99-105; the three CausalResidualUnits of
+                                            an encoder / decoder block, encoder.py:76-81, decoder.py:73-78).  The runner may launch all n as
+                                            ONE kernel (csrc/conv_rb16.hip: activations resident in LDS; an intermediate ring then receives
+                                            only the rows later calls need as history).  0 / 1: no chain starts here */
 } adk_op_desc;
 
 /* rows of ring i = hist + max_frames * rate (arena rings). */

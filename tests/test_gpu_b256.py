@@ -56,16 +56,19 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
     names = {k for _, k, _, _ in kern}
     if split16:
         # the kernels bench.py's headline number is made of -- all of them are in the programs checked here
-        assert {"conv_rl16<32>", "conv_rl16<64>", "conv_rl16_unit<32>", "conv_rl16_unit<64>", "conv_sk16<128x64>", "conv_sk16<64x64>",
-                "conv_up16<64>"} <= names, names
-        rl_taps = {(k, t) for _, k, t, _ in kern if k.startswith("conv_rl16")}
-        assert {("conv_rl16_unit<32>", 7), ("conv_rl16<32>", 11), ("conv_rl16_unit<64>", 7), ("conv_rl16<64>", 11)} <= rl_taps, rl_taps
+        assert {"conv_rb16<32>", "conv_rb16<64>", "conv_rb16<128>", "conv_sk16<64x64>", "conv_up16<64>"} <= names, names
         by_name = dict((n, k) for n, k, _, _ in kern)
         assert by_name["upsamples.3"] == "conv_up16<64>"                                       # the north-star's named kernel
-        # the residual units of encoder blocks 0-1 run as ONE launch each (K7 conv + 1x1 + residual)
-        assert by_name["encoder.conv_blocks.0.res_units.0.conv1"] == "conv_rl16_unit<32>"
-        assert by_name["encoder.conv_blocks.0.res_units.0.conv2"] == "(fused into the previous op)"
-        assert by_name["encoder.conv_blocks.1.res_units.2.conv1"] == "conv_rl16_unit<64>"
+        # every residual chain with 32 / 64 / 128 channels per group runs as ONE launch: the three residual units of encoder blocks
+        # 0-2 (6 convs each) and the residual blocks of vocoder stages 1-3 (6 grouped K11 convs each)
+        for head, C_ in (("encoder.conv_blocks.0.res_units.0.conv1", 32), ("encoder.conv_blocks.1.res_units.0.conv1", 64),
+                         ("encoder.conv_blocks.2.res_units.0.conv1", 128), ("blocks.1.convs1.0", 128), ("blocks.2.convs1.0", 64),
+                         ("blocks.3.convs1.0", 32)):
+            assert by_name[head] == f"conv_rb16<{C_}>", (head, by_name[head])
+        for tail in ("encoder.conv_blocks.0.res_units.0.conv2", "encoder.conv_blocks.2.res_units.2.conv2", "blocks.1.convs2.2", "blocks.3.convs1.1"):
+            assert by_name[tail] == "(fused into the previous op)", (tail, by_name[tail])
+        assert by_name["blocks.0.convs1.0"] == "conv_sk16<64x64>" and by_name["encoder.conv_blocks.3.res_units.0.conv1"] == "conv_sk16<64x64>"
+        assert sum(1 for _, k, _, _ in kern if k != "(fused into the previous op)") <= 45 - 5      # launches per step incl. ring writes, RVQ, lookup
     else:
         assert {"conv_rl<32>", "conv_rl<64>", "conv_sk<64x64>"} <= names, names
     # bench.py's inputs: stream s of batch j = synth_audio(SEED + j, s, HOP)
@@ -306,14 +309,15 @@ def test_fused_residual_units_are_bit_identical(gpu, ckpt_root, model, B, max_fr
     from audiodec_amd import program
     hop = HOP
     audio = np.stack([synth.synth_audio(77, s % 7, 3 * max_frames * hop) for s in range(B)])
-    old = program.FUSE_RES_UNITS
+    old, old_c = program.FUSE_RES_UNITS, program.FUSE_CHAINS
     try:
+        program.FUSE_CHAINS = False                  # (whole chains as one launch: test_residual_chains_are_bit_identical)
         program.FUSE_RES_UNITS = True
         ad_f = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
         program.FUSE_RES_UNITS = False
         ad_u = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
     finally:
-        program.FUSE_RES_UNITS = old
+        program.FUSE_RES_UNITS, program.FUSE_CHAINS = old, old_c
     kf = [ad_f.tx_encoder._encoder().describe_op(i, max_frames) for i in range(ad_f.tx_encoder._encoder().n_ops)]
     ku = [ad_u.tx_encoder._encoder().describe_op(i, max_frames) for i in range(ad_u.tx_encoder._encoder().n_ops)]
     assert kf.count("conv_rl16_unit<32>") == 3 and kf.count("conv_rl16_unit<64>") == 3 and kf.count("(fused into the previous op)") == 6, kf
@@ -327,4 +331,58 @@ def test_fused_residual_units_are_bit_identical(gpu, ckpt_root, model, B, max_fr
             yf = ad_f.decoder.decode(ad_f.rx_encoder.lookup(idx)); yu = ad_u.decoder.decode(ad_u.rx_encoder.lookup(idx))
             assert torch.equal(yf, yu), i
     from audiodec_amd import native
+    assert native.device_flags() == 0
+
+
+@pytest.mark.parametrize("model,B,max_frames,want", [
+    ("vctk_v1", 256, 1, {"conv_rb16<32>": 2, "conv_rb16<64>": 2, "conv_rb16<128>": 2}),      # the benched size: 2 streams per workgroup at 128 channels
+    ("vctk_v1", 3, 1, {"conv_rb16<32>": 2, "conv_rb16<64>": 2, "conv_rb16<128>": 2}),        # odd stream count: a workgroup with one stream
+    ("vctk_sym", 37, 1, {"conv_rb16<32>": 2, "conv_rb16<64>": 2, "conv_rb16<128>": 2}),      # encoder + symmetric decoder: ELU units (K7 + 1x1, no bias)
+    ("vctk_v0", 5, 1, {"conv_rb16<32>": 4, "conv_rb16<64>": 4, "conv_rb16<128>": 4}),        # MultiReceptiveField: K 3 / 7 / 11 blocks, one group
+    ("vctk_v2", 9, 1, {"conv_rb16<32>": 2, "conv_rb16<64>": 2, "conv_rb16<128>": 2}),        # grouped K3 blocks
+    ("vctk_v1", 4, 2, {"conv_rb16<128>": 2}),                                               # two frames per step: only the 128-channel chains still fit
+])
+def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames, want):
+    """A residual chain as ONE launch (csrc/conv_rb16.hip: HiFiGANResidualBlock.inference, residual_block.py:99-105; the three
+    CausalResidualUnits of an encoder / decoder block, residual_unit.py:78-81) against the same ops launched one by one
+    (ADK_CHAIN=0, ADK_FUSE=0): every bit of the latent and of the waveform equal over 7 calls -- full and SHORT steps mixed, so that
+    the history a chain leaves in its intermediate rings (only the rows later calls read) is what the per-op path would have
+    left, across ring wrap-around; a reset_buffer + re-warm in between."""
+    from audiodec_amd import program, native
+    hop = HOP if "c16" not in model else 320
+    old = program.FUSE_RES_UNITS, program.FUSE_CHAINS
+    try:
+        program.FUSE_RES_UNITS, program.FUSE_CHAINS = True, True
+        ad_f = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
+        program.FUSE_RES_UNITS, program.FUSE_CHAINS = False, False
+        ad_u = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
+    finally:
+        program.FUSE_RES_UNITS, program.FUSE_CHAINS = old
+    def progs(ad):
+        dec = ad.decoder
+        return [ad.tx_encoder._encoder()] + (list(dec._decoder_stages()) if hasattr(dec, "_decoder_stages") else [dec._decoder()])
+    progs_f, progs_u = progs(ad_f), progs(ad_u)
+    kf = [pr.describe_op(i, max_frames) for pr in progs_f for i in range(pr.n_ops)]
+    ku = [pr.describe_op(i, max_frames) for pr in progs_u for i in range(pr.n_ops)]
+    for name, n in want.items():
+        assert kf.count(name) >= n, (name, kf)
+    assert not any("rb16" in k or "fused" in k or "unit" in k for k in ku), ku
+    frames = [max_frames, max_frames, 1, max_frames, max_frames, 1, max_frames] if max_frames > 1 else [1] * 7
+    audio = np.stack([synth.synth_audio(91, s % 5, sum(frames) * hop) for s in range(B)])
+    pos = 0
+    with torch.no_grad():
+        for i, f in enumerate(frames):
+            if i == 4:
+                for ad in (ad_f, ad_u):              # reset_buffer() + warm-up again (bin/stream.py:59-61, 68-76)
+                    ad.tx_encoder.reset_buffer(); ad.decoder.reset_buffer()
+                    ad.tx_encoder.initial_encoder(8192, DEV)
+                    zq0 = ad.rx_encoder.initial_encoder(8192, DEV)
+                    ad.decoder.initial_decoder(zq0)
+            x = torch.from_numpy(audio[:, pos:pos + f * hop])[:, None, :].to(DEV)
+            pos += f * hop
+            zf, zu = ad_f.tx_encoder.encode(x), ad_u.tx_encoder.encode(x)
+            assert torch.equal(zf, zu), (i, float((zf - zu).abs().max()))
+            idx = ad_f.tx_encoder.quantize(zf)
+            yf = ad_f.decoder.decode(ad_f.rx_encoder.lookup(idx)); yu = ad_u.decoder.decode(ad_u.rx_encoder.lookup(idx))
+            assert torch.equal(yf, yu), (i, float((yf - yu).abs().max()))
     assert native.device_flags() == 0
