@@ -32,7 +32,25 @@
 #include <type_traits>
 #include <cstdlib>
 
+#ifndef ADK_RB16_DBG
+#define ADK_RB16_DBG 0      // tuning builds only: 1 = per-workgroup wall-clock stamps (s_memrealtime, 100 MHz) at every phase boundary of wave 0
+#endif
+
 namespace adk {
+
+#if ADK_RB16_DBG & 1
+// [launch slot 0..15][workgroup 0..1023][stamp 0..31]: stamp 0 = entry, 1 = input staged, then per conv k: 2+4k = MFMA loop done,
+// 3+4k = results in registers / ring stores issued, 4+4k = passed the first barrier, 5+4k = LDS written + second barrier passed
+__device__ unsigned long long g_rb_trace[16 * 1024 * 32];
+extern "C" int adk_debug_rb_trace(unsigned long long* out, int n) {
+    if (n > 16 * 1024 * 32) n = 16 * 1024 * 32;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rb_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+static int g_rb_launch = 0;
+#define RB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (wave == 0 && blockIdx.x < 1024) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) g_rb_trace[((size_t)(r.dbg_slot & 15) * 1024 + blockIdx.x) * 32 + (i)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RB_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -60,6 +78,7 @@ struct RbArgs {
     int rps;                             // LDS rows per stream = hm + t
     int n_tiles;                         // 32-column tiles of a full workgroup (ceil(spw * t / 32))
     float slope; int* err;
+    int dbg_slot;
 };
 
 template <int ACT>
@@ -137,6 +156,7 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const unsigned lane16 = (unsigned)lane * 16u;
+    RB_STAMP(0);
 
     const int g = blockIdx.x % r.groups;
     const int b0 = (blockIdx.x / r.groups) * r.spw;
@@ -180,6 +200,34 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
     };
     preload(r.conv[0], TA * (C / 16));
 
+    // ---- L2 warm-up.  Every workgroup of the launch walks the same weights at about the same time, and between two calls
+    // (a whole pipeline step, ~100 MB of other traffic) they have left the 4 MiB L2 of the XCD: each 2 KiB fragment pair would be
+    // a first touch -- a round trip to the Infinity Cache / HBM -- with a prefetch distance of two 16-k steps.  So the lines of
+    // a conv's weight block are TOUCHED one conv ahead (one dword per 128-byte line, result unused: the hardware has no
+    // prefetch instruction), by the waves that will stream it; the fragment loads then find them in L2.  The same for the
+    // history rows the later convs fetch from their state rings. ----
+    const int pair_w = wave - mt_w * n_pairs;           // this wave's position among the waves that share its m-tile
+    auto warm_weights = [&](const RbConv& cv) __attribute__((always_inline)) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)((g * MT + mt) * cv.ksteps) * 2048u;
+        const int nlines = cv.ksteps * 16;
+        for (int line = lane + 64 * pair_w; line < nlines; line += 64 * n_pairs)
+            (void)*reinterpret_cast<const volatile unsigned*>(base + (size_t)line * 128u);
+    };
+    warm_weights(r.conv[0]);
+    for (int k = 1; k < r.n_convs; ++k) {               // history rows [-hist_k, 0) of node k, all streams of this workgroup: 16 bytes of every 128
+        const RbNode& nd = r.node[k];
+        const int hk = r.conv[k].hist;
+        constexpr int LPR = (C * 4 + 127) / 128;        // lines per row slice of this group
+        const int total = scur * hk * LPR;
+        for (int i = tid; i < total; i += NT) {
+            const int s = i / (hk * LPR), rem = i - s * hk * LPR;
+            const int rr = rem / LPR, li = rem - rr * LPR;
+            int row = nd.cursor - hk + rr;
+            if (row < 0) row += nd.rows;
+            (void)*reinterpret_cast<const volatile unsigned*>(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 32 * li);
+        }
+    }
+
     // ---- stage the chain input: rows [-hist_0, T) of every stream, activated and split ----
     {
         const RbNode& nd = r.node[0];
@@ -215,6 +263,7 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
         }
     }
     __syncthreads();
+    RB_STAMP(1);
 
     bool bad = false;
 
@@ -331,20 +380,25 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
             for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
             float4 breg[4];
             bias_issue(k, breg);
+            warm_weights(r.conv[k + 1]);
             const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
             const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
             const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
             rb_mfma<C, TA, PF>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps) * 2048u, ah, al, m0, m1, c0, c1);
+            RB_STAMP(2 + 4 * k);
             preload(r.conv[k + 1], TB * (C / 16));              // the next conv's first fragments arrive under the epilogue
             float4 hu[NHP], hv[NHP];                            // history rows of the next conv's input, in flight during the epilogue
             hist_issue(k + 1, hu, hv);
             float h0[16], h1[16];
             finish(k, valid[0], m0, c0, breg, h0); ring_store(k + 1, 0, h0, false);
             finish(k, valid[1], m1, c1, breg, h1); ring_store(k + 1, 1, h1, false);
+            RB_STAMP(3 + 4 * k);
             __syncthreads();                            // every wave is done reading the rows of conv A's input
+            RB_STAMP(4 + 4 * k);
             lds_put(0, h0); lds_put(1, h1);
             hist_commit(k + 1, hu, hv);
             __syncthreads();
+            RB_STAMP(5 + 4 * k);
         }
         // ================= conv B: node 2u+1 -> node 2u+2, + residual (node 2u) =================
         {
@@ -357,15 +411,18 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
             for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
             float4 breg[4];
             bias_issue(k, breg);
+            if (!last) warm_weights(r.conv[kn]);
+            // the residual (this unit's input at this lane's columns) is fetched under the MFMAs of the unit's second conv
+            float4 r0[4], r1[4];
+            res_load(k - 1, 0, r0); res_load(k - 1, 1, r1);
             const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
             const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
             const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
             rb_mfma<C, TB, PF>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps) * 2048u, ah, al, m0, m1, c0, c1);
+            RB_STAMP(2 + 4 * k);
             preload(r.conv[kn], TA * (C / 16));
             float4 hu[NHP], hv[NHP];
             hist_issue(kn, hu, hv);
-            float4 r0[4], r1[4];
-            res_load(k - 1, 0, r0); res_load(k - 1, 1, r1);
             float h0[16], h1[16];
             finish(k, valid[0], m0, c0, breg, h0);
 #pragma unroll
@@ -375,11 +432,14 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) { h1[4 * qd] += r1[qd].x; h1[4 * qd + 1] += r1[qd].y; h1[4 * qd + 2] += r1[qd].z; h1[4 * qd + 3] += r1[qd].w; }
             ring_store(k + 1, 1, h1, true);
+            RB_STAMP(3 + 4 * k);
             if (!last) {
                 __syncthreads();
+                RB_STAMP(4 + 4 * k);
                 lds_put(0, h0); lds_put(1, h1);
                 hist_commit(kn, hu, hv);
                 __syncthreads();
+                RB_STAMP(5 + 4 * k);
             }
         }
     }
@@ -511,6 +571,9 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     r.n_convs = n; r.batch = a0.batch; r.t = a0.t_out; r.groups = a0.groups;
     r.spw = pl.spw; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
     r.slope = a0.slope; r.err = flags_word();
+#if ADK_RB16_DBG & 1
+    r.dbg_slot = g_rb_launch++;
+#endif
     const int act = a0.act_in;
     if (pl.C == 32) return pl.nw == 5 ? rb_by_taps<32, 5, 1>(r, pl, act, s) : rb_by_taps<32, 4, 1>(r, pl, act, s);
     if (pl.C == 64) return rb_by_taps<64, 4, 1>(r, pl, act, s);

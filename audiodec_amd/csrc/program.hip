@@ -73,6 +73,7 @@ static int ensure_workspace(Workspace& w) {
 static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
 static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
 static int g_use_chain = -1;    // ADK_CHAIN=0: residual chains run op by op (A/B against the per-op kernels)
+static int g_chain_max_c = 128; // adk_set_option("chain_max_channels")
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
@@ -143,6 +144,11 @@ using namespace adk;
 extern "C" const char* adk_last_error(void) { return g_err.c_str(); }
 extern "C" int adk_abi_version(void) { return ADK_ABI_VERSION; }
 extern "C" int adk_set_conv_cfg(int32_t cfg) { conv_mfma_force_cfg(cfg); return ADK_OK; }
+extern "C" int adk_set_option(const char* name, int32_t value) {
+    if (!name) return fail(ADK_ERR_ARG, "adk_set_option: null name");
+    if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value; return ADK_OK; }
+    return fail(ADK_ERR_ARG, std::string("adk_set_option: unknown option ") + name);
+}
 
 extern "C" int adk_streamk_plan(int64_t tiles, int32_t chunks, int32_t cap, int32_t* plan) {
     if (!plan || tiles < 1 || tiles >= (1ll << 31) / 64 || chunks < 1 || chunks > (1 << 20) || cap < 0) return fail(ADK_ERR_ARG, "adk_streamk_plan: bad argument");
@@ -387,6 +393,7 @@ static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext
     read_env();
     const int n = p->ops[i].chain;
     if (!g_use_chain || !g_use_rl || n < 2 || n > kMaxChain || i + n > (int)p->ops.size()) return false;
+    if (p->ops[i].conv.cin_g > g_chain_max_c) return false;
     for (int k = 0; k < n; ++k) {
         const adk_op_desc& o = p->ops[i + k];
         if (o.kind != ADK_OP_CONV || o.impl != ADK_IMPL_SPLIT16) return false;

@@ -51,6 +51,7 @@ SYMBOLS = {
     "adk_abi_version": (C.c_int, []),
     "adk_debug_flags": (C.c_int, [C.POINTER(_i32)]),
     "adk_set_conv_cfg": (C.c_int, [_i32]),
+    "adk_set_option": (C.c_int, [C.c_char_p, _i32]),
     "adk_streamk_plan": (C.c_int, [C.c_int64, _i32, _i32, C.POINTER(C.c_int32)]),
     "adk_streamk_range_start": (C.c_int64, [C.c_int64, _i32, C.POINTER(C.c_int32), _i32]),
     "adk_causal_conv": (C.c_int, [C.POINTER(ConvDesc), RingView, RingView, RingView, _i32, _i32, _i32, _vp]),
@@ -123,6 +124,11 @@ def check(rc, what=""):
 
 
 FLAG_BAD_INDEX, FLAG_STREAMK_TIMEOUT, FLAG_BAD_CODE, FLAG_F16_OVERFLOW = 1, 2, 4, 8
+
+
+def set_option(name, value):
+    """Process-wide tuning / test option of the library (adk_set_option in the header)."""
+    check(lib().adk_set_option(name.encode(), int(value)), "adk_set_option")
 
 
 def device_flags():

@@ -67,6 +67,13 @@ int adk_abi_version(void);
 int adk_debug_flags(int32_t* out);
 /* tuning hook: force the MFMA conv tile config (0..6), -1 = heuristic (also env ADK_CONV_CFG) */
 int adk_set_conv_cfg(int32_t cfg);
+/* tuning / test hook: named process-wide integer options, read at every launch decision.
+ *   "chain_max_channels"  residual chains (adk_op_desc.chain) run as one launch only up to this many channels per group
+ *                         (default 128 = every chain the kernel takes; 64: not the 128-channel ones; 0: never -- the ops of a
+ *                         chain are then launched one by one, as with ADK_CHAIN=0).  State rings are compatible either way:
+ *                         the value may change between two steps of a running program.
+ * ADK_ERR_ARG for an unknown name. */
+int adk_set_option(const char* name, int32_t value);
 /* Introspection of the stream-K launch schedule (pure host logic, no device needed; used by the CPU tests): a matrix-core conv
  * launch over `tiles` output tiles of `chunks` 64-deep K chunks each, allowed at most `cap` persistent workgroups (0: the library
  * default), runs plan[0] workgroups ("ranges").  plan[1] > 0: every tile is cut into plan[1] ranges (plan[1] == 2: the first takes
