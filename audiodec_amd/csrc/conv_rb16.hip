@@ -33,7 +33,10 @@
 #include <cstdlib>
 
 #ifndef ADK_RB16_DBG
-#define ADK_RB16_DBG 0      // tuning builds only: 1 = per-workgroup wall-clock stamps (s_memrealtime, 100 MHz) at every phase boundary of wave 0
+#define ADK_RB16_DBG 0      // tuning builds only: 1 = per-workgroup wall-clock stamps (s_memrealtime, 100 MHz) at every phase boundary of wave 0;
+                            // knock-outs (results are garbage): 2 = no weight loads inside the MFMA loops, 4 = no MFMAs, 8 = one B-fragment read per loop,
+                            // 16 = every workgroup reads the weight stream from a different offset (are synchronised readers of the same lines the problem?),
+                            // 32 = a barrier every 4 steps of the MFMA loops (waves of a workgroup in lockstep: their identical loads merge in L1)
 #endif
 
 namespace adk {
@@ -78,6 +81,7 @@ struct RbArgs {
     int rps;                             // LDS rows per stream = hm + t
     int n_tiles;                         // 32-column tiles of a full workgroup (ceil(spw * t / 32))
     float slope; int* err;
+    int warm;                            // touch the next conv's weights / the history rows ahead of use (launches of one workgroup per CU)
     int dbg_slot;
 };
 
@@ -111,7 +115,7 @@ __device__ __forceinline__ void rb_put8(unsigned char* dst, const float4& u, con
 // One conv of the chain for this wave's work item (m-tile, two n-tiles): the MFMA sequence of conv_rl16_kernel, straight-line
 // (a wave whose second n-tile lies past the last column computes it on clamped addresses and never stores it).
 // x0 / x1: this lane's B-fragment address for tap 0, chunk 0 of the two n-tiles; dil_rs = dilation * row stride.
-template <int C, int TAPS, int PF>
+template <int C, int TAPS, int PF, int LS>
 __device__ __forceinline__ void rb_mfma(const unsigned char* x0, const unsigned char* x1, int dil_rs,
                                         const __amdgpu_buffer_rsrc_t rsrc_w, unsigned lane16, unsigned wbase,
                                         u32x4s (&ah)[PF + 1], u32x4s (&al)[PF + 1],
@@ -119,17 +123,25 @@ __device__ __forceinline__ void rb_mfma(const unsigned char* x0, const unsigned 
     constexpr int CH = C / 16, STEPS = TAPS * CH;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-        if (s + PF < STEPS) {
+        if (s + PF < STEPS && !(ADK_RB16_DBG & 2)) {
             ah[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wbase + (unsigned)(s + PF) * 2048u, 0);
             al[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wbase + (unsigned)(s + PF) * 2048u, 0);
         }
         const int tap = s / CH, ch = s - tap * CH;
-        const int off = tap * dil_rs + 32 * ch;
-        const f16x8 Ah = rb_as_f16x8(ah[s % (PF + 1)]), Al = rb_as_f16x8(al[s % (PF + 1)]);
+        const int off = (ADK_RB16_DBG & 8) ? 0 : tap * dil_rs + 32 * ch;
+        const f16x8 Ah = rb_as_f16x8(ah[(ADK_RB16_DBG & 2) ? 0 : s % (PF + 1)]), Al = rb_as_f16x8(al[(ADK_RB16_DBG & 2) ? 0 : s % (PF + 1)]);
         const f16x8 b0h = *reinterpret_cast<const f16x8*>(x0 + off);
         const f16x8 b0l = *reinterpret_cast<const f16x8*>(x0 + off + 2 * C);
         const f16x8 b1h = *reinterpret_cast<const f16x8*>(x1 + off);
         const f16x8 b1l = *reinterpret_cast<const f16x8*>(x1 + off + 2 * C);
+        if (ADK_RB16_DBG & 4) {
+            m0[0] += (float)b0h[0] + (float)b0l[1] + (float)b1h[2] + (float)b1l[3] + (float)Ah[0] + (float)Al[1];
+            continue;
+        }
+        // LS > 0: the waves of the workgroup re-align every LS steps (a bare s_barrier: no memory is handed over).  Measured on the
+        // 128-channel chains -- 4 waves streaming four different 180 KiB weight blocks -- the MFMA loop takes HALF the time when the
+        // waves (and with them all workgroups of the launch) walk the weights in step: 38 -> 19 us per conv (profiles/r3_rb16_timeline.md)
+        if (LS > 0 && (s % LS) == LS - 1 && s + 1 < STEPS) __builtin_amdgcn_s_barrier();
         m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, m0, 0, 0, 0);
         m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1h, m1, 0, 0, 0);
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, c0, 0, 0, 0);
@@ -141,13 +153,14 @@ __device__ __forceinline__ void rb_mfma(const unsigned char* x0, const unsigned 
 
 // NW waves per workgroup, each with at most ONE work item (m-tile of 32 output channels, pair of 32-column tiles).
 // SMAX = most streams a workgroup takes (sizes the register staging of the history rows).
-template <int C, int ACT, int TA, int TB, int NW, int SMAX>
-__global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(RbArgs r) {
+// WPS = waves per SIMD the register budget is cut for (2: 256 registers, 3: 168, 4: 128); PF = weight prefetch distance in 16-k
+// steps; EARLY_RES: the residual is fetched before the second conv's MFMA loop (32 more registers live through it).
+template <int C, int ACT, int TA, int TB, int NW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+__global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
     constexpr int C8 = C / 8;
     constexpr int MT = C / 32;
     constexpr int NT = 64 * NW;
-    constexpr int PF = 2;
     constexpr bool BIAS_LDS = C < 128;                 // bias of every conv staged in LDS (the 128-channel variant has no LDS to spare, but registers)
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
@@ -171,8 +184,9 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
     // masked where something is STORED (valid[]) -- no divergent control flow around the MFMA loops, no values kept alive
     // across them by a branch ----
     const int n_pairs = (r.n_tiles + 1) >> 1;
-    const int mt_w = wave / n_pairs;
-    const int nt0 = 2 * (wave - mt_w * n_pairs);
+    const int item = wave;
+    const int mt_w = item / n_pairs;
+    const int nt0 = 2 * (item - mt_w * n_pairs);
     const bool has_item = mt_w < MT && nt0 < n_tiles;
     const int mt = min(mt_w, MT - 1);
     bool valid[2]; int sj[2], tj[2], lrow[2];
@@ -206,15 +220,15 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
     // a conv's weight block are TOUCHED one conv ahead (one dword per 128-byte line, result unused: the hardware has no
     // prefetch instruction), by the waves that will stream it; the fragment loads then find them in L2.  The same for the
     // history rows the later convs fetch from their state rings. ----
-    const int pair_w = wave - mt_w * n_pairs;           // this wave's position among the waves that share its m-tile
+    const int pair_w = has_item ? item - mt_w * n_pairs : 0;   // this wave's position among the waves that share its m-tile
     auto warm_weights = [&](const RbConv& cv) __attribute__((always_inline)) {
         const unsigned char* base = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)((g * MT + mt) * cv.ksteps) * 2048u;
         const int nlines = cv.ksteps * 16;
         for (int line = lane + 64 * pair_w; line < nlines; line += 64 * n_pairs)
             (void)*reinterpret_cast<const volatile unsigned*>(base + (size_t)line * 128u);
     };
-    warm_weights(r.conv[0]);
-    for (int k = 1; k < r.n_convs; ++k) {               // history rows [-hist_k, 0) of node k, all streams of this workgroup: 16 bytes of every 128
+    if (r.warm) warm_weights(r.conv[0]);
+    for (int k = 1; k < (r.warm ? r.n_convs : 0); ++k) { // history rows [-hist_k, 0) of node k, all streams of this workgroup: 16 bytes of every 128
         const RbNode& nd = r.node[k];
         const int hk = r.conv[k].hist;
         constexpr int LPR = (C * 4 + 127) / 128;        // lines per row slice of this group
@@ -234,10 +248,11 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
         const int h0 = r.conv[0].hist;
         const int per = (h0 + T) * C8;                  // 8-channel pieces per stream
         const int total = scur * per;
-        for (int i0 = tid; i0 < total; i0 += 2 * NT) {
-            float4 u[2], v[2]; int dst[2];
+        constexpr int SB = 4;                           // pieces per thread in flight: one memory round trip per SB * NT pieces
+        for (int i0 = tid; i0 < total; i0 += SB * NT) {
+            float4 u[SB], v[SB]; int dst[SB];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < SB; ++k) {
                 const int i = i0 + k * NT;
                 dst[k] = -1;
                 if (i < total) {
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < SB; ++k)
                 if (dst[k] >= 0) rb_put8<C, ACT>(xs + dst[k], u[k], v[k], r.slope);
         }
         if constexpr (BIAS_LDS) {
@@ -380,11 +395,11 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
             for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
             float4 breg[4];
             bias_issue(k, breg);
-            warm_weights(r.conv[k + 1]);
+            if (r.warm) warm_weights(r.conv[k + 1]);
             const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
             const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
             const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
-            rb_mfma<C, TA, PF>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps) * 2048u, ah, al, m0, m1, c0, c1);
+            rb_mfma<C, TA, PF, LS>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u, ah, al, m0, m1, c0, c1);
             RB_STAMP(2 + 4 * k);
             preload(r.conv[k + 1], TB * (C / 16));              // the next conv's first fragments arrive under the epilogue
             float4 hu[NHP], hv[NHP];                            // history rows of the next conv's input, in flight during the epilogue
@@ -411,18 +426,20 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
             for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
             float4 breg[4];
             bias_issue(k, breg);
-            if (!last) warm_weights(r.conv[kn]);
-            // the residual (this unit's input at this lane's columns) is fetched under the MFMAs of the unit's second conv
+            if (!last && r.warm) warm_weights(r.conv[kn]);
+            // the residual (this unit's input at this lane's columns) is fetched under the MFMAs of the unit's second conv where the
+            // register budget allows, else right after them
             float4 r0[4], r1[4];
-            res_load(k - 1, 0, r0); res_load(k - 1, 1, r1);
+            if constexpr (EARLY_RES) { res_load(k - 1, 0, r0); res_load(k - 1, 1, r1); }
             const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
             const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
             const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
-            rb_mfma<C, TB, PF>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps) * 2048u, ah, al, m0, m1, c0, c1);
+            rb_mfma<C, TB, PF, LS>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u, ah, al, m0, m1, c0, c1);
             RB_STAMP(2 + 4 * k);
             preload(r.conv[kn], TA * (C / 16));
             float4 hu[NHP], hv[NHP];
             hist_issue(kn, hu, hv);
+            if constexpr (!EARLY_RES) { res_load(k - 1, 0, r0); res_load(k - 1, 1, r1); }
             float h0[16], h1[16];
             finish(k, valid[0], m0, c0, breg, h0);
 #pragma unroll
@@ -447,6 +464,8 @@ __global__ __launch_bounds__(64 * NW, (C >= 128 ? 2 : 3)) void conv_rb16_kernel(
 }
 
 struct RbPlan { int C, ta, tb, nw, spw, n_tiles, hm, rps; size_t lds; long long blocks; };
+
+int rb_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 int rb_streams_per_wg(int C, int batch, int t) {
     static int env = -1;                                // tuning: ADK_RB16_SPW (streams per workgroup of the 128-channel chains)
@@ -521,9 +540,9 @@ bool conv_rb16_fusable(const ConvArgs* c, int n) {
 }
 
 namespace {
-template <int C, int ACT, int TA, int TB, int NW, int SMAX>
+template <int C, int ACT, int TA, int TB, int NW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
 int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
-    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NW, SMAX>;
+    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NW, SMAX, WPS, PF, EARLY_RES, LS>;
     if (pl.lds > 64 * 1024) {
         static bool attr_set_dev[kMaxDevices] = {};     // function attributes are per device
         bool& attr_set = attr_set_dev[current_device()];
@@ -537,12 +556,12 @@ int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
     return ADK_OK;
 }
 
-template <int C, int NW, int SMAX>
+template <int C, int NW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
 int rb_by_taps(const RbArgs& r, const RbPlan& pl, int act, hipStream_t s) {
-    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NW, SMAX>(r, pl, s);
-    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NW, SMAX>(r, pl, s);
-    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NW, SMAX>(r, pl, s);
-    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NW, SMAX>(r, pl, s);
+    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
 }
 }  // namespace
 
@@ -571,13 +590,31 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     r.n_convs = n; r.batch = a0.batch; r.t = a0.t_out; r.groups = a0.groups;
     r.spw = pl.spw; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
     r.slope = a0.slope; r.err = flags_word();
+    // L2 warm-up where a conv's weight block is a few loads per lane (32 / 64 channels: the 32-channel vocoder chain 281 -> 200 us,
+    // the encoder chains 10-20 %); the 128-channel chains would spend 22 line touches per lane and conv on it (17 us of prologue,
+    // no gain in the loops: profiles/r3_rb16_timeline.md) -- their waves walk the weights in lockstep instead (LS)
+    static const int warm_env = rb_knob("ADK_RB16_WARM", -1);
+    r.warm = warm_env >= 0 ? warm_env : (pl.C <= 64);
 #if ADK_RB16_DBG & 1
     r.dbg_slot = g_rb_launch++;
 #endif
     const int act = a0.act_in;
-    if (pl.C == 32) return pl.nw == 5 ? rb_by_taps<32, 5, 1>(r, pl, act, s) : rb_by_taps<32, 4, 1>(r, pl, act, s);
-    if (pl.C == 64) return rb_by_taps<64, 4, 1>(r, pl, act, s);
-    return rb_by_taps<128, 4, 2>(r, pl, act, s);
+    // register budgets: 32 channels -- 168 registers (ONE 5-wave workgroup per CU: the hardware starts every workgroup's waves on
+    // the same SIMD, so a second one does not fit beside it; at 128 registers two fit but both double up on that SIMD, and a
+    // variant that spread the fifth item over 8-wave workgroups was slower still: 240 k vs 228 k vs 212 k frames/s in the
+    // pipeline, profiles/r3_rb16_timeline.md); 64 channels -- 168 (three 4-wave workgroups); 128 channels -- 256 (two), which
+    // buys a prefetch distance of 6 steps, and the waves re-align every LS steps
+    static const int v32 = rb_knob("ADK_RB16_V32", 1);                 // tuning: 2 = 5 waves at 128 registers, residual fetched after the loop
+    static const int ls128 = rb_knob("ADK_RB16_LS", 4);                // tuning: lockstep interval of the 128-channel chains (0, 2, 4, 8)
+    if (pl.C == 32) {
+        if (pl.nw == 5) return v32 == 2 ? rb_by_taps<32, 5, 1, 4, 2, false, 0>(r, pl, act, s) : rb_by_taps<32, 5, 1, 3, 2, true, 0>(r, pl, act, s);
+        return rb_by_taps<32, 4, 1, 3, 2, true, 0>(r, pl, act, s);
+    }
+    if (pl.C == 64) return rb_by_taps<64, 4, 1, 3, 2, true, 0>(r, pl, act, s);
+    if (ls128 == 0) return rb_by_taps<128, 4, 2, 2, 6, true, 0>(r, pl, act, s);
+    if (ls128 == 2) return rb_by_taps<128, 4, 2, 2, 6, true, 2>(r, pl, act, s);
+    if (ls128 == 8) return rb_by_taps<128, 4, 2, 2, 6, true, 8>(r, pl, act, s);
+    return rb_by_taps<128, 4, 2, 2, 6, true, 4>(r, pl, act, s);
 }
 
 const char* conv_rb16_name(const ConvArgs* c, int n) {

@@ -73,7 +73,8 @@ static int ensure_workspace(Workspace& w) {
 static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
 static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
 static int g_use_chain = -1;    // ADK_CHAIN=0: residual chains run op by op (A/B against the per-op kernels)
-static int g_chain_max_c = 128; // adk_set_option("chain_max_channels")
+static int g_chain_max_c = -1;  // adk_set_option("chain_max_channels") / ADK_CHAIN_MAXC
+static int g_chain_min_c = -1;  // adk_set_option("chain_min_channels") / ADK_CHAIN_MINC
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
@@ -82,6 +83,8 @@ static void read_env() {
     if (g_use_rl < 0) { const char* e = getenv("ADK_CONV_RL"); g_use_rl = e ? atoi(e) : 1; }
     if (g_use_up < 0) { const char* e = getenv("ADK_CONV_UP16"); g_use_up = e ? atoi(e) : 1; }
     if (g_use_chain < 0) { const char* e = getenv("ADK_CHAIN"); g_use_chain = e ? atoi(e) : 1; }
+    if (g_chain_max_c < 0) { const char* e = getenv("ADK_CHAIN_MAXC"); g_chain_max_c = e ? atoi(e) : 128; }
+    if (g_chain_min_c < 0) { const char* e = getenv("ADK_CHAIN_MINC"); g_chain_min_c = e ? atoi(e) : 0; }
 }
 
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
@@ -146,7 +149,9 @@ extern "C" int adk_abi_version(void) { return ADK_ABI_VERSION; }
 extern "C" int adk_set_conv_cfg(int32_t cfg) { conv_mfma_force_cfg(cfg); return ADK_OK; }
 extern "C" int adk_set_option(const char* name, int32_t value) {
     if (!name) return fail(ADK_ERR_ARG, "adk_set_option: null name");
-    if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value; return ADK_OK; }
+    read_env();
+    if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value < 0 ? 0 : value; return ADK_OK; }
+    if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
     return fail(ADK_ERR_ARG, std::string("adk_set_option: unknown option ") + name);
 }
 
@@ -393,7 +398,7 @@ static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext
     read_env();
     const int n = p->ops[i].chain;
     if (!g_use_chain || !g_use_rl || n < 2 || n > kMaxChain || i + n > (int)p->ops.size()) return false;
-    if (p->ops[i].conv.cin_g > g_chain_max_c) return false;
+    if (p->ops[i].conv.cin_g > g_chain_max_c || p->ops[i].conv.cin_g < g_chain_min_c) return false;
     for (int k = 0; k < n; ++k) {
         const adk_op_desc& o = p->ops[i + k];
         if (o.kind != ADK_OP_CONV || o.impl != ADK_IMPL_SPLIT16) return false;

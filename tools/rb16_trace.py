@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Phase timeline of the residual-chain kernel (csrc/conv_rb16.hip) from a DEBUG build of the library.
 
-  python tools/rb16_trace.py [streams=256]
+  python tools/rb16_trace.py [streams=256] [dbg flags=1]        (--build f1 f2 ...: only build the debug libraries)
 
-Builds audiodec_amd/csrc/*.hip with -DADK_RB16_DBG=1 into /tmp/adk_dbg/libaudiodec_hip.so (the product library is untouched),
+Builds csrc/conv_rb16.hip with -DADK_RB16_DBG=<flags> (1 = stamps; +2 no weight loads, +4 no MFMAs, +8 one B read: knock-outs)
+into tools/dbg/rb<flags>/libaudiodec_hip.so (the product library is untouched),
 loads vctk_v1 at `streams` streams, runs a few steps and prints, for the chain launches of the LAST step, the median over
 workgroups of the time wave 0 spent in each phase (s_memrealtime stamps, 10 ns ticks -> us)."""
 import ctypes as C
@@ -17,17 +18,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_debug():
-    out = "/tmp/adk_dbg"
+def build_debug(flags=1):
+    """Debug build of the library with -DADK_RB16_DBG=<flags> under tools/dbg/ (not tracked; it travels to the GPU box with the
+    snapshot, so build it where the compiler is -- `python tools/rb16_trace.py --build 1 3 5 9` -- and run it there)."""
+    out = os.path.join(ROOT, "tools", "dbg", f"rb{flags}")
     os.makedirs(out, exist_ok=True)
     lib = os.path.join(out, "libaudiodec_hip.so")
     srcs = sorted(glob.glob(os.path.join(ROOT, "audiodec_amd", "csrc", "*.hip")))
-    objs = []
-    procs = []
+    objs, procs = [], []
     for s in srcs:
-        o = os.path.join(out, os.path.basename(s)[:-4] + ".o")
+        base = os.path.basename(s)[:-4]
+        if base != "conv_rb16":                     # every other object is the product build's
+            objs.append(os.path.join(ROOT, "audiodec_amd", "csrc", ".obj", base + ".o"))
+            continue
+        o = os.path.join(out, base + ".o")
         objs.append(o)
-        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DADK_RB16_DBG=1",
+        procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-DADK_RB16_DBG={flags}",
                                        "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o]))
     for p in procs:
         assert p.wait() == 0
@@ -36,8 +42,14 @@ def build_debug():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--build":
+        for f in sys.argv[2:]:
+            print(build_debug(int(f)))
+        return
+    flags = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    os.environ["ADK_LIB_PATH"] = build_debug()
+    lib_path = os.path.join(ROOT, "tools", "dbg", f"rb{flags}", "libaudiodec_hip.so")
+    os.environ["ADK_LIB_PATH"] = lib_path if os.path.exists(lib_path) else build_debug(flags)
     os.environ["ADK_SPLIT16"] = "1"
     os.environ.setdefault("ADK_VOCODER_STAGES", "1")
     import numpy as np
