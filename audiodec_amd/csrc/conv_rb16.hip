@@ -112,14 +112,13 @@ __device__ __forceinline__ void rb_put8(unsigned char* dst, const float4& u, con
     *reinterpret_cast<f16x8*>(dst + 2 * C) = lo;
 }
 
-// One conv of the chain for this wave's work item (m-tile, two n-tiles): the MFMA sequence of conv_rl16_kernel, straight-line
-// (a wave whose second n-tile lies past the last column computes it on clamped addresses and never stores it).
-// x0 / x1: this lane's B-fragment address for tap 0, chunk 0 of the two n-tiles; dil_rs = dilation * row stride.
-template <int C, int TAPS, int PF, int LS>
-__device__ __forceinline__ void rb_mfma(const unsigned char* x0, const unsigned char* x1, int dil_rs,
+// One conv of the chain for this wave's work item (m-tile, NA n-tiles): the MFMA sequence of conv_rl16_kernel per n-tile,
+// straight-line (an n-tile past the last column is computed on clamped addresses and never stored).
+// x[j]: this lane's B-fragment address for tap 0, chunk 0 of n-tile j; dil_rs = dilation * row stride.
+template <int C, int TAPS, int PF, int LS, int NA, int NTW>
+__device__ __forceinline__ void rb_mfma(const unsigned char* const (&x)[NTW], int dil_rs,
                                         const __amdgpu_buffer_rsrc_t rsrc_w, unsigned lane16, unsigned wbase,
-                                        u32x4s (&ah)[PF + 1], u32x4s (&al)[PF + 1],
-                                        f32x16& m0, f32x16& m1, f32x16& c0, f32x16& c1) {
+                                        u32x4s (&ah)[PF + 1], u32x4s (&al)[PF + 1], f32x16 (&m)[NTW], f32x16 (&c)[NTW]) {
     constexpr int CH = C / 16, STEPS = TAPS * CH;
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
@@ -130,37 +129,39 @@ __device__ __forceinline__ void rb_mfma(const unsigned char* x0, const unsigned 
         const int tap = s / CH, ch = s - tap * CH;
         const int off = (ADK_RB16_DBG & 8) ? 0 : tap * dil_rs + 32 * ch;
         const f16x8 Ah = rb_as_f16x8(ah[(ADK_RB16_DBG & 2) ? 0 : s % (PF + 1)]), Al = rb_as_f16x8(al[(ADK_RB16_DBG & 2) ? 0 : s % (PF + 1)]);
-        const f16x8 b0h = *reinterpret_cast<const f16x8*>(x0 + off);
-        const f16x8 b0l = *reinterpret_cast<const f16x8*>(x0 + off + 2 * C);
-        const f16x8 b1h = *reinterpret_cast<const f16x8*>(x1 + off);
-        const f16x8 b1l = *reinterpret_cast<const f16x8*>(x1 + off + 2 * C);
-        if (ADK_RB16_DBG & 4) {
-            m0[0] += (float)b0h[0] + (float)b0l[1] + (float)b1h[2] + (float)b1l[3] + (float)Ah[0] + (float)Al[1];
-            continue;
+        f16x8 bh[NA], bl[NA];
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            bh[j] = *reinterpret_cast<const f16x8*>(x[j] + off);
+            bl[j] = *reinterpret_cast<const f16x8*>(x[j] + off + 2 * C);
         }
+        // per accumulator the order is hi*hi | hi*lo, lo*hi -- the same as conv_rl16; the n-tiles are interleaved so that no MFMA
+        // waits for the one before it
+#pragma unroll
+        for (int j = 0; j < NA; ++j) m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bh[j], m[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bl[j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh[j], c[j], 0, 0, 0);
         // LS > 0: the waves of the workgroup re-align every LS steps (a bare s_barrier: no memory is handed over).  Measured on the
         // 128-channel chains -- 4 waves streaming four different 180 KiB weight blocks -- the MFMA loop takes HALF the time when the
         // waves (and with them all workgroups of the launch) walk the weights in step: 38 -> 19 us per conv (profiles/r3_rb16_timeline.md)
         if (LS > 0 && (s % LS) == LS - 1 && s + 1 < STEPS) __builtin_amdgcn_s_barrier();
-        m0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0h, m0, 0, 0, 0);
-        m1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1h, m1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b0l, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, b1l, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b0h, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, b1h, c1, 0, 0, 0);
     }
 }
 
-// NW waves per workgroup, each with at most ONE work item (m-tile of 32 output channels, pair of 32-column tiles).
-// SMAX = most streams a workgroup takes (sizes the register staging of the history rows).
-// WPS = waves per SIMD the register budget is cut for (2: 256 registers, 3: 168, 4: 128); PF = weight prefetch distance in 16-k
-// steps; EARLY_RES: the residual is fetched before the second conv's MFMA loop (32 more registers live through it).
-template <int C, int ACT, int TA, int TB, int NW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
-__global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
+// 4 waves per workgroup: wave w works on m-tile w / WM (WM = 4 / m-tiles waves share an m-tile) and on up to NTW consecutive 32-column
+// tiles of it.  SMAX = most streams a workgroup takes (sizes the register staging of the history rows).
+// WPS = waves per SIMD the register budget is cut for (2: 256 registers, 3: 168); PF = weight prefetch distance in 16-k steps;
+// EARLY_RES: the residual is fetched before the second conv's MFMA loop (16 registers per n-tile live through it);
+// LS: lockstep interval (rb_mfma).
+template <int C, int ACT, int TA, int TB, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+__global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
     constexpr int C8 = C / 8;
     constexpr int MT = C / 32;
-    constexpr int NT = 64 * NW;
+    constexpr int NW = 4, NT = 64 * NW;
+    constexpr int WM = NW / MT;                         // waves that share an m-tile (and its weight stream)
     constexpr bool BIAS_LDS = C < 128;                 // bias of every conv staged in LDS (the 128-channel variant has no LDS to spare, but registers)
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
@@ -176,24 +177,23 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
     const int scur = min(r.spw, r.batch - b0);
     const int T = r.t;
     const int ncols = scur * T;
-    const int n_tiles = (ncols + 31) >> 5;
     float* bias_lds = reinterpret_cast<float*>(xs + (size_t)r.spw * r.rps * RS);      // [n_convs][C]
 
-    // ---- this wave's work item; this lane's two GEMM columns.  Everything below is straight-line for every wave: a wave
-    // without an item (fewer columns than a full workgroup) and columns past the end compute on clamped addresses and are
-    // masked where something is STORED (valid[]) -- no divergent control flow around the MFMA loops, no values kept alive
-    // across them by a branch ----
-    const int n_pairs = (r.n_tiles + 1) >> 1;
-    const int item = wave;
-    const int mt_w = item / n_pairs;
-    const int nt0 = 2 * (item - mt_w * n_pairs);
-    const bool has_item = mt_w < MT && nt0 < n_tiles;
-    const int mt = min(mt_w, MT - 1);
-    bool valid[2]; int sj[2], tj[2], lrow[2];
+    // ---- this wave's work item: m-tile mt, n-tiles [first, first + ntw).  The tiles of an m-tile are dealt to its WM waves as
+    // evenly as they go; who gets the odd ones rotates with the workgroup, because the hardware puts wave w of EVERY workgroup
+    // on the same SIMD (0, 2, 1, 3) -- without the rotation the same SIMD would carry the longer item in every co-resident
+    // workgroup.  Everything below is straight-line for every wave: n-tiles the wave does not have and columns past the end are
+    // computed on clamped addresses and masked where something is STORED (valid[]). ----
+    const int mt = wave / WM, wi = wave - mt * WM;
+    const int base = r.n_tiles / WM, rem = r.n_tiles - base * WM;
+    const int pos = (wi + WM - (int)((blockIdx.x + blockIdx.x / 256u) % WM)) % WM;
+    const int ntw = base + (pos < rem ? 1 : 0);
+    const int first = pos * base + min(pos, rem);
+    bool valid[NTW]; int sj[NTW], tj[NTW], lrow[NTW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = (nt0 + j) * 32 + l31;
-        valid[j] = has_item && n < ncols;
+    for (int j = 0; j < NTW; ++j) {
+        const int n = (first + j) * 32 + l31;
+        valid[j] = j < ntw && n < ncols;
         const int nc = min(n, ncols - 1);
         sj[j] = nc / T; tj[j] = nc - sj[j] * T;
         lrow[j] = sj[j] * r.rps + r.hm + tj[j];
@@ -220,12 +220,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
     // a conv's weight block are TOUCHED one conv ahead (one dword per 128-byte line, result unused: the hardware has no
     // prefetch instruction), by the waves that will stream it; the fragment loads then find them in L2.  The same for the
     // history rows the later convs fetch from their state rings. ----
-    const int pair_w = has_item ? item - mt_w * n_pairs : 0;   // this wave's position among the waves that share its m-tile
     auto warm_weights = [&](const RbConv& cv) __attribute__((always_inline)) {
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)((g * MT + mt) * cv.ksteps) * 2048u;
+        const unsigned char* wbp = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)((g * MT + mt) * cv.ksteps) * 2048u;
         const int nlines = cv.ksteps * 16;
-        for (int line = lane + 64 * pair_w; line < nlines; line += 64 * n_pairs)
-            (void)*reinterpret_cast<const volatile unsigned*>(base + (size_t)line * 128u);
+        for (int line = lane + 64 * wi; line < nlines; line += 64 * WM)
+            (void)*reinterpret_cast<const volatile unsigned*>(wbp + (size_t)line * 128u);
     };
     if (r.warm) warm_weights(r.conv[0]);
     for (int k = 1; k < (r.warm ? r.n_convs : 0); ++k) { // history rows [-hist_k, 0) of node k, all streams of this workgroup: 16 bytes of every 128
@@ -234,8 +233,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
         constexpr int LPR = (C * 4 + 127) / 128;        // lines per row slice of this group
         const int total = scur * hk * LPR;
         for (int i = tid; i < total; i += NT) {
-            const int s = i / (hk * LPR), rem = i - s * hk * LPR;
-            const int rr = rem / LPR, li = rem - rr * LPR;
+            const int s = i / (hk * LPR), rem_ = i - s * hk * LPR;
+            const int rr = rem_ / LPR, li = rem_ - rr * LPR;
             int row = nd.cursor - hk + rr;
             if (row < 0) row += nd.rows;
             (void)*reinterpret_cast<const volatile unsigned*>(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 32 * li);
@@ -256,8 +255,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
                 const int i = i0 + k * NT;
                 dst[k] = -1;
                 if (i < total) {
-                    const int s = i / per, rem = i - s * per;
-                    const int rr = rem / C8, c8 = rem - rr * C8;
+                    const int s = i / per, rem_ = i - s * per;
+                    const int rr = rem_ / C8, c8 = rem_ - rr * C8;
                     int row = nd.cursor - h0 + rr;
                     if (row < 0) row += nd.rows;
                     if (row >= nd.rows) row -= nd.rows;
@@ -292,8 +291,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
             const int i = tid + q * NT;
             hu[q] = hv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < total) {
-                const int s = i / per, rem = i - s * per;
-                const int rr = rem / C8, c8 = rem - rr * C8;
+                const int s = i / per, rem_ = i - s * per;
+                const int rr = rem_ / C8, c8 = rem_ - rr * C8;
                 int row = nd.cursor - hk + rr;
                 if (row < 0) row += nd.rows;
                 const float4* p = reinterpret_cast<const float4*>(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 8 * c8);
@@ -308,8 +307,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
         for (int q = 0; q < NHP; ++q) {
             const int i = tid + q * NT;
             if (i < total) {
-                const int s = i / per, rem = i - s * per;
-                const int rr = rem / C8, c8 = rem - rr * C8;
+                const int s = i / per, rem_ = i - s * per;
+                const int rr = rem_ / C8, c8 = rem_ - rr * C8;
                 rb_put8<C, ACT>(xs + (s * r.rps + r.hm - hk + rr) * RS + 16 * c8, hu[q], hv[q], r.slope);
             }
         }
@@ -382,6 +381,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
             *reinterpret_cast<f16x4*>(row + 2 * C + 2 * ml) = lo;
         }
     };
+    // the MFMA loop of one conv over this wave's n-tiles (a wave with one tile less than NTW runs the shorter loop)
+    auto conv_loop = [&](auto taps_c, const RbConv& cv, f32x16 (&m)[NTW], f32x16 (&c)[NTW]) __attribute__((always_inline)) {
+        constexpr int TAPS = decltype(taps_c)::value;
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
+        const unsigned wbase = (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u;
+        const unsigned char* x[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) x[j] = xs + (lrow[j] - cv.hist) * RS + 16 * lh;
+        if (NTW > 2 && ntw < NTW) rb_mfma<C, TAPS, PF, LS, (NTW > 2 ? NTW - 1 : NTW), NTW>(x, cv.dil * RS, rsrc_w, lane16, wbase, ah, al, m, c);
+        else rb_mfma<C, TAPS, PF, LS, NTW, NTW>(x, cv.dil * RS, rsrc_w, lane16, wbase, ah, al, m, c);
+    };
 
     const int units = r.n_convs >> 1;
 #pragma unroll 1
@@ -390,27 +400,27 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
         {
             const int k = 2 * u;
             const RbConv cv = r.conv[k];
-            f32x16 m0, m1, c0, c1;
+            f32x16 m[NTW], c[NTW];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { m[j][e] = 0.f; c[j][e] = 0.f; }
             float4 breg[4];
             bias_issue(k, breg);
             if (r.warm) warm_weights(r.conv[k + 1]);
-            const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
-            const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
-            const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
-            rb_mfma<C, TA, PF, LS>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u, ah, al, m0, m1, c0, c1);
+            conv_loop(std::integral_constant<int, TA>(), cv, m, c);
             RB_STAMP(2 + 4 * k);
             preload(r.conv[k + 1], TB * (C / 16));              // the next conv's first fragments arrive under the epilogue
             float4 hu[NHP], hv[NHP];                            // history rows of the next conv's input, in flight during the epilogue
             hist_issue(k + 1, hu, hv);
-            float h0[16], h1[16];
-            finish(k, valid[0], m0, c0, breg, h0); ring_store(k + 1, 0, h0, false);
-            finish(k, valid[1], m1, c1, breg, h1); ring_store(k + 1, 1, h1, false);
+            float h[NTW][16];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) { finish(k, valid[j], m[j], c[j], breg, h[j]); ring_store(k + 1, j, h[j], false); }
             RB_STAMP(3 + 4 * k);
             __syncthreads();                            // every wave is done reading the rows of conv A's input
             RB_STAMP(4 + 4 * k);
-            lds_put(0, h0); lds_put(1, h1);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) lds_put(j, h[j]);
             hist_commit(k + 1, hu, hv);
             __syncthreads();
             RB_STAMP(5 + 4 * k);
@@ -421,39 +431,44 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
             const RbConv cv = r.conv[k];
             const bool last = u + 1 == units;
             const int kn = last ? k : k + 1;                    // (the last conv prefetches its own data again: harmless, keeps the code straight-line)
-            f32x16 m0, m1, c0, c1;
+            f32x16 m[NTW], c[NTW];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { m0[e] = 0.f; m1[e] = 0.f; c0[e] = 0.f; c1[e] = 0.f; }
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { m[j][e] = 0.f; c[j][e] = 0.f; }
             float4 breg[4];
             bias_issue(k, breg);
             if (!last && r.warm) warm_weights(r.conv[kn]);
             // the residual (this unit's input at this lane's columns) is fetched under the MFMAs of the unit's second conv where the
             // register budget allows, else right after them
-            float4 r0[4], r1[4];
-            if constexpr (EARLY_RES) { res_load(k - 1, 0, r0); res_load(k - 1, 1, r1); }
-            const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
-            const unsigned char* x0 = xs + (lrow[0] - cv.hist) * RS + 16 * lh;
-            const unsigned char* x1 = xs + (lrow[1] - cv.hist) * RS + 16 * lh;
-            rb_mfma<C, TB, PF, LS>(x0, x1, cv.dil * RS, rsrc_w, lane16, (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u, ah, al, m0, m1, c0, c1);
+            float4 rr[NTW][4];
+            if constexpr (EARLY_RES) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) res_load(k - 1, j, rr[j]);
+            }
+            conv_loop(std::integral_constant<int, TB>(), cv, m, c);
             RB_STAMP(2 + 4 * k);
             preload(r.conv[kn], TA * (C / 16));
             float4 hu[NHP], hv[NHP];
             hist_issue(kn, hu, hv);
-            if constexpr (!EARLY_RES) { res_load(k - 1, 0, r0); res_load(k - 1, 1, r1); }
-            float h0[16], h1[16];
-            finish(k, valid[0], m0, c0, breg, h0);
+            if constexpr (!EARLY_RES) {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) { h0[4 * qd] += r0[qd].x; h0[4 * qd + 1] += r0[qd].y; h0[4 * qd + 2] += r0[qd].z; h0[4 * qd + 3] += r0[qd].w; }
-            ring_store(k + 1, 0, h0, true);
-            finish(k, valid[1], m1, c1, breg, h1);
+                for (int j = 0; j < NTW; ++j) res_load(k - 1, j, rr[j]);
+            }
+            float h[NTW][16];
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) { h1[4 * qd] += r1[qd].x; h1[4 * qd + 1] += r1[qd].y; h1[4 * qd + 2] += r1[qd].z; h1[4 * qd + 3] += r1[qd].w; }
-            ring_store(k + 1, 1, h1, true);
+            for (int j = 0; j < NTW; ++j) {
+                finish(k, valid[j], m[j], c[j], breg, h[j]);
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) { h[j][4 * qd] += rr[j][qd].x; h[j][4 * qd + 1] += rr[j][qd].y; h[j][4 * qd + 2] += rr[j][qd].z; h[j][4 * qd + 3] += rr[j][qd].w; }
+                ring_store(k + 1, j, h[j], true);
+            }
             RB_STAMP(3 + 4 * k);
             if (!last) {
                 __syncthreads();
                 RB_STAMP(4 + 4 * k);
-                lds_put(0, h0); lds_put(1, h1);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) lds_put(j, h[j]);
                 hist_commit(kn, hu, hv);
                 __syncthreads();
                 RB_STAMP(5 + 4 * k);
@@ -463,16 +478,19 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_rb16_kernel(RbArgs r) {
     if (bad) atomicOr(r.err, 8);
 }
 
-struct RbPlan { int C, ta, tb, nw, spw, n_tiles, hm, rps; size_t lds; long long blocks; };
+struct RbPlan { int C, ta, tb, ntw, spw, n_tiles, hm, rps; size_t lds; long long blocks; };
 
 int rb_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 int rb_streams_per_wg(int C, int batch, int t) {
-    static int env = -1;                                // tuning: ADK_RB16_SPW (streams per workgroup of the 128-channel chains)
-    if (env < 0) { const char* e = getenv("ADK_RB16_SPW"); env = e ? atoi(e) : 0; }
+    static const int env128 = rb_knob("ADK_RB16_SPW", 0);        // tuning: streams per workgroup of the 128-channel chains
+    static const int env64 = rb_knob("ADK_RB16_SPW64", 0);       // ... of the 64-channel chains
     int s = (C == 128) ? 2 : 1;
-    if (env > 0 && C == 128) s = std::min(env, 2);
-    while (s > 1 && (s > batch || s * t > 64)) --s;
+    if (env128 > 0 && C == 128) s = env128;
+    if (env64 > 0 && C == 64) s = env64;
+    const int wm = 4 / (C / 32);                                  // waves per m-tile, up to 4 n-tiles each
+    const int max_ntw = C == 128 ? 2 : 4;                         // n-tiles per wave the instantiations go up to
+    while (s > 1 && (s > batch || (s * t + 31) / 32 > max_ntw * wm)) --s;
     return s;
 }
 
@@ -481,17 +499,17 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     const ConvArgs& a0 = c[0];
     pl.C = a0.cin_g; pl.ta = a0.taps; pl.tb = c[1].taps;
     const int T = a0.t_out;
+    const int wm = 4 / (pl.C / 32);
     pl.spw = rb_streams_per_wg(pl.C, a0.batch, T);
     pl.n_tiles = (pl.spw * T + 31) / 32;
-    const int items = (pl.C / 32) * ((pl.n_tiles + 1) / 2);
-    if (items > 5) return false;
-    pl.nw = items == 5 ? 5 : 4;
+    pl.ntw = std::max(2, (pl.n_tiles + wm - 1) / wm);            // n-tiles per wave: 2, 3 or 4
+    if (pl.ntw > 4 || (pl.C == 128 && pl.ntw > 2)) return false;
     pl.hm = 0;
     for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
     if (pl.hm > kRbMaxHist) return false;
     pl.rps = pl.hm + T;
     pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (pl.C < 128 ? (size_t)n * pl.C * 4 : 0);
-    if (pl.lds > 160 * 1024) return false;
+    if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 2 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
     pl.blocks = (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups;
     return pl.blocks <= 0x7fffffffLL;
 }
@@ -540,9 +558,9 @@ bool conv_rb16_fusable(const ConvArgs* c, int n) {
 }
 
 namespace {
-template <int C, int ACT, int TA, int TB, int NW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+template <int C, int ACT, int TA, int TB, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
 int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
-    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NW, SMAX, WPS, PF, EARLY_RES, LS>;
+    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NTW, SMAX, WPS, PF, EARLY_RES, LS>;
     if (pl.lds > 64 * 1024) {
         static bool attr_set_dev[kMaxDevices] = {};     // function attributes are per device
         bool& attr_set = attr_set_dev[current_device()];
@@ -551,17 +569,17 @@ int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(64 * NW), pl.lds, s, r);
+    hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(256), pl.lds, s, r);
     ADK_HIP_CHECK(hipGetLastError());
     return ADK_OK;
 }
 
-template <int C, int NW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+template <int C, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
 int rb_by_taps(const RbArgs& r, const RbPlan& pl, int act, hipStream_t s) {
-    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
-    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
-    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
-    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
 }
 }  // namespace
 
@@ -599,22 +617,23 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     r.dbg_slot = g_rb_launch++;
 #endif
     const int act = a0.act_in;
-    // register budgets: 32 channels -- 168 registers (ONE 5-wave workgroup per CU: the hardware starts every workgroup's waves on
-    // the same SIMD, so a second one does not fit beside it; at 128 registers two fit but both double up on that SIMD, and a
-    // variant that spread the fifth item over 8-wave workgroups was slower still: 240 k vs 228 k vs 212 k frames/s in the
-    // pipeline, profiles/r3_rb16_timeline.md); 64 channels -- 168 (three 4-wave workgroups); 128 channels -- 256 (two), which
-    // buys a prefetch distance of 6 steps, and the waves re-align every LS steps
-    static const int v32 = rb_knob("ADK_RB16_V32", 1);                 // tuning: 2 = 5 waves at 128 registers, residual fetched after the loop
-    static const int ls128 = rb_knob("ADK_RB16_LS", 4);                // tuning: lockstep interval of the 128-channel chains (0, 2, 4, 8)
+    // Register budgets.  Two n-tiles per wave: 168 registers (three 4-wave workgroups per CU), the residual fetched under the second
+    // conv's MFMAs; three: 256 (two workgroups), residual early; four: 256, residual after the loop.  128 channels: 256, which also
+    // buys a prefetch distance of 6 steps, and the waves re-align every 4 steps (LS).
+    // (32 channels used to run as 5 waves x 2 tiles: the hardware starts every workgroup's waves on the same SIMD, so one SIMD
+    // carried two waves of every co-resident workgroup and a second 5-wave workgroup did not even fit at 168 registers --
+    // profiles/r3_rb16_timeline.md.  Now 4 waves x (3, 3, 2, 2) tiles, the odd tiles rotating with the workgroup.)
     if (pl.C == 32) {
-        if (pl.nw == 5) return v32 == 2 ? rb_by_taps<32, 5, 1, 4, 2, false, 0>(r, pl, act, s) : rb_by_taps<32, 5, 1, 3, 2, true, 0>(r, pl, act, s);
-        return rb_by_taps<32, 4, 1, 3, 2, true, 0>(r, pl, act, s);
+        if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, 2, true, 0>(r, pl, act, s);
+        if (pl.ntw == 3) return rb_by_taps<32, 3, 1, 2, 2, true, 0>(r, pl, act, s);
+        return rb_by_taps<32, 4, 1, 2, 2, false, 0>(r, pl, act, s);
     }
-    if (pl.C == 64) return rb_by_taps<64, 4, 1, 3, 2, true, 0>(r, pl, act, s);
-    if (ls128 == 0) return rb_by_taps<128, 4, 2, 2, 6, true, 0>(r, pl, act, s);
-    if (ls128 == 2) return rb_by_taps<128, 4, 2, 2, 6, true, 2>(r, pl, act, s);
-    if (ls128 == 8) return rb_by_taps<128, 4, 2, 2, 6, true, 8>(r, pl, act, s);
-    return rb_by_taps<128, 4, 2, 2, 6, true, 4>(r, pl, act, s);
+    if (pl.C == 64) {
+        if (pl.ntw == 2 && pl.spw == 1) return rb_by_taps<64, 2, 1, 3, 2, true, 0>(r, pl, act, s);
+        if (pl.ntw <= 3) return rb_by_taps<64, 3, 2, 2, 2, true, 0>(r, pl, act, s);
+        return rb_by_taps<64, 4, 2, 2, 2, false, 0>(r, pl, act, s);
+    }
+    return rb_by_taps<128, 2, 2, 2, 6, true, 4>(r, pl, act, s);
 }
 
 const char* conv_rb16_name(const ConvArgs* c, int n) {
