@@ -72,9 +72,55 @@ def build_oracle(model, batch):
     return tx, rx, dec
 
 
+def reference_conv_table(module):
+    """Every convolution of a reference model as the reference built it: module path -> [kind, cin, cout, K, stride, dilation,
+    groups, has bias, streaming history length].  Read off the reference's OWN module tree (named_modules), independently of
+    audiodec_amd/arch.py -- the list the oracle and the product both enumerate their layers from."""
+    table, pads = {}, {}
+    for name, m in module.named_modules():
+        if isinstance(m, torch.nn.ConvTranspose1d):
+            table[name] = ["convT", m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0], m.dilation[0], m.groups, m.bias is not None]
+        elif isinstance(m, torch.nn.Conv1d):
+            table[name] = ["conv", m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0], m.dilation[0], m.groups, m.bias is not None]
+        if hasattr(m, "pad_buffer"):                       # CausalConv1d / CausalConvTranspose1d (layers/conv_layer.py:141, :182)
+            pads[name] = int(m.pad_buffer.shape[-1])
+    for name, row in table.items():
+        parent = name.rsplit(".", 1)[0]
+        row.append(pads.get(parent, 0))
+    return table
+
+
+def arch_conv_table(specs):
+    """The same table from audiodec_amd/arch.py's ConvSpec list."""
+    return {s.wkey("weight")[:-len(".weight")]: ["convT" if s.kind == "convT" else "conv", s.cin, s.cout, s.k, s.stride, s.dilation,
+                                                 s.groups, bool(s.bias), s.pad] for s in specs}
+
+
+def check_arch(ad, model):
+    """arch.py's enumeration of the convolutions == the reference's module tree, for the encoder half and the decoder half of
+    `model`; returns the reference tables (stored in the fixture, so that the CPU suite can repeat the comparison without
+    the reference: tests/test_oracle_golden.py::test_arch_enumeration_matches_the_reference_module_tree)."""
+    from audiodec_amd import arch
+    _, enc_tag, _, dec_tag, _ = configs.alias(model)
+    _, _, pe = configs.experiment(enc_tag)
+    mt_d, _, pd = configs.experiment(dec_tag)
+    ref_enc = reference_conv_table(ad.tx_encoder)
+    ref_dec = reference_conv_table(ad.decoder)
+    ours_enc = arch_conv_table(arch.autoencoder_encoder_convs(pe) + arch.autoencoder_decoder_convs(pe))
+    ours_dec = arch_conv_table(arch.hifigan_convs(pd) if mt_d in ("HiFiGAN", "UnivNet") else
+                               arch.autoencoder_encoder_convs(pd) + arch.autoencoder_decoder_convs(pd))
+    for what, ref, ours in (("encoder", ref_enc, ours_enc), ("decoder", ref_dec, ours_dec)):
+        assert set(ref) == set(ours), f"{model} {what}: conv modules differ: only reference {sorted(set(ref) - set(ours))[:5]}, only arch.py {sorted(set(ours) - set(ref))[:5]}"
+        for k in ref:
+            assert ref[k] == ours[k], f"{model} {what} {k}: reference {ref[k]} != arch.py {ours[k]}"
+    return {"encoder": ref_enc, "decoder": ref_dec}
+
+
 def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
+    import json
     torch.set_num_threads(4)
     sr, ad = load_reference(ref_audiodec, model)
+    conv_tables = check_arch(ad, model)
     hop = ad.get_hop_length(configs.checkpoint_paths(model)[1])
     total = one_shot_len if one_shot_len is not None else sum(schedule) * hop
     chunks = [one_shot_len] if one_shot_len is not None else [c * hop for c in schedule]
@@ -134,7 +180,8 @@ def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
         out, model=model, seed=SEED, n_streams=n_streams, hop=hop, sample_rate=sr,
         schedule=np.asarray(schedule if one_shot_len is None else [], np.int64),
         one_shot_len=-1 if one_shot_len is None else one_shot_len,
-        z=z.numpy(), idx=idx.numpy(), zq=zq.numpy(), y=y.numpy(), margin=om.numpy())
+        z=z.numpy(), idx=idx.numpy(), zq=zq.numpy(), y=y.numpy(), margin=om.numpy(),
+        ref_convs=np.asarray(json.dumps(conv_tables, sort_keys=True)))
     print(f"{name}: frames {z.shape[-1]} z std {float(z.std()):.3f} |y|max {float(y.abs().max()):.3f} "
           f"min top-2 margin {float(om.min()):.3e} distinct idx {len(torch.unique(idx))} "
           f"-> {os.path.getsize(out)} B  (oracle == reference: exact)")
@@ -239,23 +286,28 @@ OFFLINE = {
     "vctk_sym_offline": ("vctk_sym", [1500, 901]),
 }
 
+# 65 frames in 29 calls: mostly single frames (the streaming steady state: the fused residual-chain kernels), with longer calls
+# in between (which the product chops into max_frames pieces and, beyond one frame, runs op by op) -- every model sees both
+# paths alternate on the same state
+LONG = [1, 2, 1, 3, 1, 1, 4, 1, 1, 2, 1, 1, 8, 1, 1, 1, 3, 1, 1, 1, 2, 1, 1, 5, 1, 1, 1, 16, 1]
+
 CASES = {
     # name: (model alias, n_streams, chunk schedule in frames, one-shot length in samples)
-    "vctk_sym_stream": ("vctk_sym", 2, [1, 2, 1, 3], None),
-    "vctk_v1_stream": ("vctk_v1", 2, [1, 2, 1, 3], None),
+    "vctk_sym_stream": ("vctk_sym", 2, LONG, None),
+    "vctk_v1_stream": ("vctk_v1", 2, LONG, None),
     "libritts_sym_file": ("libritts_sym", 1, None, 24000),          # BASELINE config 1 (demoFile)
-    "vctk_v0_stream": ("vctk_v0", 1, [1, 2], None),
-    "vctk_v2_stream": ("vctk_v2", 1, [1, 2], None),
-    "vctk_activate_sym_stream": ("vctk_activate_sym", 1, [1, 2], None),
-    "vctk_c16h320_sym_stream": ("vctk_c16h320_sym", 1, [1, 2], None),
+    "vctk_v0_stream": ("vctk_v0", 1, LONG, None),
+    "vctk_v2_stream": ("vctk_v2", 1, LONG, None),
+    "vctk_activate_sym_stream": ("vctk_activate_sym", 1, LONG, None),
+    "vctk_c16h320_sym_stream": ("vctk_c16h320_sym", 1, LONG, None),
     # the remaining aliases of utils/audiodec.py:109-179 (round 2)
-    "libritts_v1_stream": ("libritts_v1", 1, [2, 1], None),
-    "vctk_denoise_stream": ("vctk_denoise", 1, [1, 2], None),
-    "vctk_univ_stream": ("vctk_univ", 1, [1, 2], None),
-    "vctk_univ_sym_stream": ("vctk_univ_sym", 1, [2, 1], None),
+    "libritts_v1_stream": ("libritts_v1", 1, LONG, None),
+    "vctk_denoise_stream": ("vctk_denoise", 1, LONG, None),
+    "vctk_univ_stream": ("vctk_univ", 1, LONG, None),
+    "vctk_univ_sym_stream": ("vctk_univ_sym", 1, LONG, None),
     # HiFiGANResidualBlock(use_additional_convs=False) (residual_block.py:100-105), grouped (v1-shaped) and MRF (v0-shaped)
-    "test_v1_noaddl_stream": ("test_v1_noaddl", 2, [1, 2, 1], None),
-    "test_v0_noaddl_stream": ("test_v0_noaddl", 1, [1, 2], None),
+    "test_v1_noaddl_stream": ("test_v1_noaddl", 2, LONG, None),
+    "test_v0_noaddl_stream": ("test_v0_noaddl", 1, LONG, None),
 }
 
 

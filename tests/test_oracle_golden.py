@@ -107,6 +107,47 @@ def test_oracle_matches_reference_fixture(golden_dir, name):
     assert np.abs(y - g["y"]).max() < TOL
 
 
+@pytest.mark.parametrize("name", [c for c in CASES])
+def test_arch_enumeration_matches_the_reference_module_tree(golden_dir, name):
+    """audiodec_amd/arch.py is the list of convolutions BOTH the product and the oracle enumerate their layers from.  The
+    fixtures carry the same table read off the reference's own module tree (named_modules() of the loaded reference models:
+    kind, channels, K, stride, dilation, groups, bias, streaming history length -- tests/golden/make_golden.py, where the
+    comparison is also asserted against the live reference): an enumeration mistake shared by product and oracle cannot hide
+    behind outputs that happen to agree."""
+    import json
+    from audiodec_amd import arch
+    g = _load(golden_dir, name)
+    ref = json.loads(str(g["ref_convs"]))
+    model = str(g["model"])
+    _, enc_tag, _, dec_tag, _ = configs.alias(model)
+    _, _, pe = configs.experiment(enc_tag)
+    mt_d, _, pd = configs.experiment(dec_tag)
+
+    def table(specs):
+        return {s.wkey("weight")[:-len(".weight")]: ["convT" if s.kind == "convT" else "conv", s.cin, s.cout, s.k, s.stride, s.dilation,
+                                                     s.groups, bool(s.bias), s.pad] for s in specs}
+    ours = {"encoder": table(arch.autoencoder_encoder_convs(pe) + arch.autoencoder_decoder_convs(pe)),
+            "decoder": table(arch.hifigan_convs(pd) if mt_d in ("HiFiGAN", "UnivNet") else
+                             arch.autoencoder_encoder_convs(pd) + arch.autoencoder_decoder_convs(pd))}
+    for half in ("encoder", "decoder"):
+        assert len(ref[half]) >= 20
+        assert set(ref[half]) == set(ours[half]), (half, sorted(set(ref[half]) ^ set(ours[half]))[:6])
+        for k, row in ref[half].items():
+            assert row == ours[half][k], (half, k, row, ours[half][k])
+
+
+def test_stream_fixtures_carry_volume(golden_dir):
+    """Every streaming fixture holds >= 64 frames per stream (>= 512 RVQ decisions, hundreds of distinct codes), single-frame and
+    multi-frame calls mixed."""
+    for name in CASES:
+        g = _load(golden_dir, name)
+        if int(g["one_shot_len"]) > 0:
+            continue
+        sched = [int(c) for c in g["schedule"]]
+        assert sum(sched) >= 64 and sched.count(1) >= 16 and max(sched) >= 8, (name, sched)
+        assert g["idx"].shape[-1] == sum(sched) and len(np.unique(g["idx"])) >= 400, (name, len(np.unique(g["idx"])))
+
+
 def test_oracle_layers_match_reference_fixture(golden_dir):
     g = _load(golden_dir, "ops")
     for n, (ci, co, k, s, d, gr, b, L1, L2) in enumerate(C.CONVS):
