@@ -26,6 +26,7 @@ class AudioDec(AudioCodec):
         receptive_length: int = 8192,  # actual number is 7209 for symAD_vctk_48000_hop300
         num_streams: int = 1,
         max_frames: int = 16,
+        guard: bool = True,
     ):
         # The signature keeps the reference's 'cpu' defaults (utils/audiodec.py:20-30) so that callers port unchanged, but
         # this package has no CPU compute path: 'cpu' becomes the first HIP device (with a warning), and without a HIP
@@ -36,6 +37,9 @@ class AudioDec(AudioCodec):
             native.require_gpu(d)
         self.num_streams = num_streams
         self.max_frames = max_frames
+        # guard=True: every program step is checked on the device and a split-f16 range overflow is repaired in place by the
+        # exact-f32 kernels (stream_generator.set_guard); False for callers that keep several steps in flight (bench.py)
+        self.guard = guard
 
     def _load_encoder(self, checkpoint):
         # utils/audiodec.py:32-42
@@ -46,7 +50,7 @@ class AudioDec(AudioCodec):
             raise NotImplementedError(f"Encoder type {config['model_type']} is not supported!")
         encoder = encoder(**config["generator_params"])
         encoder.load_state_dict(torch.load(checkpoint, map_location="cpu")["model"]["generator"])
-        return encoder.configure(self.num_streams, self.max_frames)
+        return encoder.configure(self.num_streams, self.max_frames).set_guard(self.guard)
 
     def _load_decoder(self, checkpoint):
         # utils/audiodec.py:44-56
@@ -59,7 +63,7 @@ class AudioDec(AudioCodec):
             raise NotImplementedError(f"Decoder {config['model_type']} is not supported!")
         decoder = decoder(**config["generator_params"])
         decoder.load_state_dict(torch.load(checkpoint, map_location="cpu")["model"]["generator"])
-        return decoder.configure(self.num_streams, self.max_frames)
+        return decoder.configure(self.num_streams, self.max_frames).set_guard(self.guard)
 
     def load_receiver(self, encoder_checkpoint, decoder_checkpoint):
         # bin/stream.py:65-77.  The receiver-side encoder only supplies the codebook and the warm-up

@@ -29,7 +29,9 @@ struct ConvArgs {
     int act_in, act_out; float slope;
     int batch, t_out, n_total;      // n_total = batch * t_out GEMM columns
     int ktot;                       // taps * cin_g
+    int* err = nullptr;             // sticky device flag word the launch reports to: its program's (adk_program_flags), or nullptr = the device-wide word
 };
+inline int* conv_err_word(const ConvArgs& a);
 
 // expm1(x) for x <= 0 (the negative branch of torch.nn.ELU, layers/activation_function.py:18-22 -> torch.nn.ELU).  The library
 // expm1f costs ~30 VALU instructions per element, and the ELU convs convert every activation they stage: measured with
@@ -84,6 +86,9 @@ int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // spli
 int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 int* flags_word();                                   // address of the sticky debug/error flags ON THE CURRENT DEVICE
+inline int* conv_err_word(const ConvArgs& a) { return a.err ? a.err : flags_word(); }
+// OR of the flag words of every live program on `device` (each fetched and cleared atomically); the device must be current and idle
+int fetch_clear_program_flags(int device, int* acc);
 constexpr int kMaxDevices = 64;
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
 // Makes `device` current for the lifetime of the object (programs are bound to the device they were created on,

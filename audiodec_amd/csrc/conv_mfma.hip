@@ -784,7 +784,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     sk.flags = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws.ptr) + ws.flags_offset);
     sk.epoch = ++ws.epoch;
     if (sk.epoch == 0) sk.epoch = ++ws.epoch;
-    sk.err = flags_word();
+    sk.err = conv_err_word(a);
     if (lds > 64 * 1024) {
         static bool attr_set_dev[kMaxDevices] = {};      // function attributes are per device
         bool& attr_set = attr_set_dev[current_device()];

@@ -607,7 +607,7 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     }
     r.n_convs = n; r.batch = a0.batch; r.t = a0.t_out; r.groups = a0.groups;
     r.spw = pl.spw; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
-    r.slope = a0.slope; r.err = flags_word();
+    r.slope = a0.slope; r.err = conv_err_word(a0);
     // L2 warm-up where a conv's weight block is a few loads per lane (32 / 64 channels: the 32-channel vocoder chain 281 -> 200 us,
     // the encoder chains 10-20 %); the 128-channel chains would spend 22 line touches per lane and conv on it (17 us of prologue,
     // no gain in the loops: profiles/r3_rb16_timeline.md) -- their waves walk the weights in lockstep instead (LS)

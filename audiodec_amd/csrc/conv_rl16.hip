@@ -504,7 +504,7 @@ int launch_rl16(const ConvArgs& a, hipStream_t s, int tt) {
     rl.mt32_per_g = a.cout_g / 32;
     rl.ksteps = (a.ktot + 63) / 64 * 4;
     rl.w_bytes = (unsigned)((unsigned long long)a.groups * rl.mt32_per_g * rl.ksteps * 2048ull);
-    rl.err = flags_word();
+    rl.err = conv_err_word(a);
     rl.tt = tt;
     rl.tiles_per_stream = (a.t_out + tt - 1) / tt;
     constexpr int RS = 4 * C + 16;
@@ -574,7 +574,7 @@ int launch_rl16_fused(const ConvArgs& a, const ConvArgs& a2, hipStream_t s, int 
     rl.mt32_per_g = a.cout_g / 32;
     rl.ksteps = (a.ktot + 63) / 64 * 4;
     rl.w_bytes = (unsigned)((unsigned long long)a.groups * rl.mt32_per_g * rl.ksteps * 2048ull);
-    rl.err = flags_word();
+    rl.err = conv_err_word(a);
     rl.tt = tt;
     rl.tiles_per_stream = (a.t_out + tt - 1) / tt;
     rl.w2 = a2.wfrag; rl.bias2 = a2.bias;

@@ -158,7 +158,7 @@ int launch_conv_up16(const ConvArgs& a, hipStream_t s) {
     u.chunks_per_stream = (a.t_out + 127) / 128;
     u.m_tiles = a.cout_g / 32;
     u.inv_cout_real = 1.0f / (float)a.cout_real;
-    u.err = flags_word();
+    u.err = conv_err_word(a);
     const long long blocks = (long long)a.batch * u.chunks_per_stream;
     if (blocks > 0x7fffffffLL) return fail(ADK_ERR_SHAPE, "conv: too many workgroups");
     const size_t lds = (size_t)u.m_tiles * UP_KSTEPS * 2048 + (size_t)u.m_tiles * 32 * sizeof(float);

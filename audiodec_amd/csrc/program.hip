@@ -7,6 +7,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace adk {
 
@@ -250,6 +251,8 @@ struct adk_program {
     const float* weights = nullptr; int64_t weights_floats = 0;
     float* arena = nullptr; int64_t arena_floats = 0;
     Workspace ws;
+    int* flags = nullptr;           // this program's sticky device flag word (bits as adk_debug_flags): what its launches report to
+    int* flags_out = nullptr;       // staging word for adk_program_flags
     bool profiling = false;
     bool fresh = true;              // no step since create / reset (ADK_OP_HIST_REPLICATE runs only then)
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
@@ -262,6 +265,33 @@ struct adk_program {
     std::vector<hipGraphExec_t> gexec;
     long long replays = 0, captures = 0;
 };
+
+static std::mutex g_prog_mu;
+static std::vector<adk_program*> g_programs;          // live programs (for adk_debug_flags)
+
+__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); }
+
+static int program_fetch_clear(adk_program* p, hipStream_t s, int* v) {
+    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, s, p->flags, p->flags_out);
+    ADK_HIP_CHECK(hipGetLastError());
+    ADK_HIP_CHECK(hipMemcpyAsync(v, p->flags_out, sizeof(int), hipMemcpyDeviceToHost, s));
+    ADK_HIP_CHECK(hipStreamSynchronize(s));
+    return ADK_OK;
+}
+
+namespace adk {
+int fetch_clear_program_flags(int device, int* acc) {
+    std::lock_guard<std::mutex> lk(g_prog_mu);
+    for (adk_program* p : g_programs) {
+        if (p->device != device) continue;
+        int v = 0;
+        const int rc = program_fetch_clear(p, nullptr, &v);
+        if (rc != ADK_OK) return rc;
+        *acc |= v;
+    }
+    return ADK_OK;
+}
+}  // namespace adk
 
 extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const adk_ring_desc* rings, int32_t n_rings,
                                   int32_t batch, int32_t max_frames, const float* weights, int64_t weights_floats,
@@ -341,6 +371,16 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
     {
         int rc = ensure_workspace(p->ws);
         if (rc != ADK_OK) { delete p; return rc; }
+        if (hipMalloc(reinterpret_cast<void**>(&p->flags), 2 * sizeof(int)) != hipSuccess || hipMemset(p->flags, 0, 2 * sizeof(int)) != hipSuccess) {
+            if (p->ws.ptr) (void)hipFree(p->ws.ptr);
+            delete p;
+            return fail(ADK_ERR_HIP, "program_create: cannot allocate the flag word");
+        }
+        p->flags_out = p->flags + 1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_prog_mu);
+        g_programs.push_back(p);
     }
     *out = p;
     return ADK_OK;
@@ -348,9 +388,14 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
 
 extern "C" void adk_program_destroy(adk_program* p) {
     if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_prog_mu);
+        g_programs.erase(std::remove(g_programs.begin(), g_programs.end(), p), g_programs.end());
+    }
     DeviceGuard guard(p->device);
     for (hipGraphExec_t g : p->gexec) if (g) (void)hipGraphExecDestroy(g);
     if (p->ws.ptr) (void)hipFree(p->ws.ptr);
+    if (p->flags) (void)hipFree(p->flags);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
 }
@@ -378,7 +423,9 @@ static int op_conv_args(adk_program* p, int i, int frames, void* const* ext, Con
     adk_ring_view out = view_of(p, o.out_ring, frames, ext, o.out_ch_off);
     adk_ring_view res; memset(&res, 0, sizeof(res));
     if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
-    return build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+    const int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
+    a.err = p->flags;
+    return rc;
 }
 
 // Can ops i, i+1 (a residual unit: conv -> 1x1 + residual) run as one launch for a `frames`-hop step?
@@ -636,6 +683,26 @@ extern "C" int adk_program_reset(adk_program* p, void* stream) {
         p->cursor[i] = 0;
     }
     p->fresh = true;
+    return ADK_OK;
+}
+
+extern "C" int adk_program_flags(adk_program* p, void* stream, int32_t* out) {
+    if (!p || !out) return fail(ADK_ERR_ARG, "program_flags: null argument");
+    DeviceGuard guard(p->device);
+    int v = 0;
+    const int rc = program_fetch_clear(p, static_cast<hipStream_t>(stream), &v);
+    *out = v;
+    return rc;
+}
+
+extern "C" int adk_program_rewind(adk_program* p, int32_t frames) {
+    if (!p) return fail(ADK_ERR_ARG, "program_rewind: null program");
+    if (frames <= 0 || frames > p->max_frames) return fail(ADK_ERR_SHAPE, "program_rewind: frames must be in [1, max_frames]");
+    for (size_t i = 0; i < p->rings.size(); ++i)
+        if (p->rings[i].external < 0) {
+            const long long back = ((long long)frames * p->rings[i].rate) % p->rows[i];
+            p->cursor[i] = (int32_t)(((long long)p->cursor[i] - back + p->rows[i]) % p->rows[i]);
+        }
     return ADK_OK;
 }
 

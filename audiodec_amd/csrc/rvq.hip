@@ -420,6 +420,8 @@ extern "C" int adk_debug_flags(int32_t* out) {
         int v = 0;
         ADK_HIP_CHECK(hipMemcpy(&v, scratch[d], sizeof(int), hipMemcpyDeviceToHost));
         all |= v;
+        const int rc = fetch_clear_program_flags(d, &all);       // programs report to words of their own (adk_program_flags)
+        if (rc != ADK_OK) return rc;
     }
     if (out) *out = all;
     return ADK_OK;

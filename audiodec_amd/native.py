@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -73,6 +73,8 @@ SYMBOLS = {
     "adk_program_destroy": (None, [_vp]),
     "adk_program_step": (C.c_int, [_vp, _i32, C.POINTER(_vp), _i32, _vp]),
     "adk_program_reset": (C.c_int, [_vp, _vp]),
+    "adk_program_flags": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
+    "adk_program_rewind": (C.c_int, [_vp, _i32]),
     "adk_program_get_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "adk_program_set_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "adk_program_describe_op": (C.c_int, [_vp, _i32, _i32, C.c_char_p, _i32]),
@@ -142,7 +144,11 @@ def raise_on_device_flags(where=""):
     """Turn a device-side failure into the exception the reference's PyTorch path would have raised (or the closest
     one).  Called where the facade synchronises anyway (payload / waveform leaves the device, end of an utterance,
     streamer tick); kernels never stop a launch sequence, they record the failure in a sticky word."""
-    v = device_flags()
+    raise_for_flags(device_flags(), where)
+
+
+def raise_for_flags(v, where=""):
+    """The exception for a flag word (adk_debug_flags / adk_program_flags bits); nothing for 0."""
     if not v:
         return
     pre = f"{where}: " if where else ""
@@ -153,7 +159,9 @@ def raise_on_device_flags(where=""):
         raise ValueError(pre + "an index that is not a code of its stage was packed (wire format)")
     if v & FLAG_F16_OVERFLOW:
         raise NativeError(pre + "a split-f16 conv produced non-finite values: an operand beyond the f16 range "
-                                "(|v| > 65504) or non-finite input; results since the last check are invalid")
+                                "(|v| > 65504) or non-finite input; results since the last check are invalid "
+                                "(synchronous callers recover automatically -- guard=True, the default of AudioDec; an asynchronous "
+                                "pipeline that runs into this should use the exact-f32 kernels: ADK_SPLIT16=0 / set_split16(False))")
     if v & FLAG_STREAMK_TIMEOUT:
         raise NativeError(pre + "a stream-K conv workgroup timed out waiting for a partial tile; results since the "
                                 "last check are invalid")

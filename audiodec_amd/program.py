@@ -456,10 +456,15 @@ def graph_ring_hist(hist, rate, max_frames):
 class HipProgram:
     """One model half on one HIP device for `batch` streams (C++ adk_program + arena + weights)."""
 
-    def __init__(self, builder, batch, max_frames, device, graph=False):
+    def __init__(self, builder, batch, max_frames, device, graph=False, twin=None):
         self.dev = native.require_gpu(device)
         self.lib = native.lib()
         self.batch, self.max_frames = int(batch), int(max_frames)
+        self.split16, self.offline = bool(builder.split16), bool(builder.offline)
+        self.twin_builder = twin          # () -> Builder of the same lowering with the exact-f32 kernels (demote())
+        self.graph_requested = bool(graph)
+        self.demoted = False
+        self.workgroups = 0
         if graph:
             for r in builder.rings:
                 if r["external"] < 0:
@@ -515,6 +520,36 @@ class HipProgram:
 
     def reset(self):
         native.check(self.lib.adk_program_reset(self.h, native.current_stream(self.dev)), "adk_program_reset")
+
+    def flags(self):
+        """Wait for the current HIP stream, return this program's sticky device flag word and clear it (adk_program_flags)."""
+        v = C.c_int32(0)
+        native.check(self.lib.adk_program_flags(self.h, native.current_stream(self.dev), C.byref(v)), "adk_program_flags")
+        return int(v.value)
+
+    def rewind(self, frames):
+        """Ring cursors back by the `frames` hops of the step just taken (adk_program_rewind): the step can be repeated."""
+        native.check(self.lib.adk_program_rewind(self.h, int(frames)), "adk_program_rewind")
+
+    def demote(self):
+        """The exact-f32 twin of this program takes over IN PLACE (every reference to this object stays valid): same ops,
+        same rings, same arena layout, weights packed for the f32 kernels; the state (arena + cursors) is carried across.
+        Used when a split-f16 step reports an operand beyond the f16 range: rewind(), demote(), repeat the step."""
+        if self.twin_builder is None or not self.split16 or self.demoted:
+            raise native.NativeError("this program has no exact-f32 twin to fall back to")
+        twin = HipProgram(self.twin_builder(), self.batch, self.max_frames, self.dev, graph=self.graph_requested)
+        if twin.arena_floats != self.arena_floats or twin.n_rings != self.n_rings or twin.ring_rows != self.ring_rows:
+            raise native.NativeError("the exact-f32 twin has a different state layout")
+        twin.arena.copy_(self.arena)
+        twin.set_cursors(self.cursors())
+        if self.workgroups:
+            twin.set_workgroups(self.workgroups)
+        mine = dict(self.__dict__)
+        for k in ("h", "weights", "weight_floats", "arena", "_ops", "op_names", "n_ops", "ring_meta", "ring_rows", "flops_per_frame",
+                  "graph", "state_floats_per_stream", "arena_floats", "n_rings", "_ext"):
+            self.__dict__[k] = twin.__dict__[k]
+            twin.__dict__[k] = mine[k]                 # the split-f16 program is destroyed with `twin`
+        self.split16, self.demoted = False, True
 
     def cursors(self):
         c = (C.c_int32 * self.n_rings)()
@@ -578,6 +613,7 @@ class HipProgram:
 
     def set_workgroups(self, workgroups):
         """Persistent workgroups per stream-K launch (0 = whole chip); see adk_program_set_workgroups."""
+        self.workgroups = int(workgroups)
         native.check(self.lib.adk_program_set_workgroups(self.h, int(workgroups)), "adk_program_set_workgroups")
 
     def set_profiling(self, on):

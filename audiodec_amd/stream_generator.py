@@ -54,7 +54,12 @@ class _StreamBase:
         self.max_frames = 16
         self.offline = False
         self.workgroups = 0
-        self.split16 = os.environ.get("ADK_SPLIT16", "0") == "1"
+        # arithmetic of the matrix-core convs: split-f16 operands (f16 hi + f16 lo/2048, three f16 MFMAs per product sum, f32
+        # accumulation: 2^-22 relative per operand, measured error below the f32 MFMA chain's) unless ADK_SPLIT16=0 asks for the
+        # exact-f32 kernels.  An operand beyond the f16 range (|v| > 65504) is caught on the device; with `guard` the step is
+        # repeated on the exact-f32 twin of the program, which then stays in charge (set_guard)
+        self.split16 = os.environ.get("ADK_SPLIT16", "1") == "1"
+        self.guard = os.environ.get("ADK_GUARD", "1") == "1"
         self.graph = os.environ.get("ADK_GRAPH", "0") == "1"
         self._warm = {}
 
@@ -79,10 +84,20 @@ class _StreamBase:
             self._drop_programs()
         return self
 
+    def set_guard(self, on=True):
+        """guard=True (default): every program step is followed by a check of the program's device flag word (one stream
+        synchronisation per step).  A split-f16 step that met an operand beyond the f16 range is REPEATED on the exact-f32
+        kernels -- ring cursors rewound, state carried over, same inputs: exact, because a step only reads history rows earlier
+        steps wrote -- and the program stays on them from then on (a warning says so); any other device-side failure raises
+        here, at the step that caused it.  guard=False: nothing synchronises; failures surface at the caller's next
+        native.raise_on_device_flags() (asynchronous multi-stream pipelines: bench.py)."""
+        self.guard = bool(on)
+        return self
+
     def set_split16(self, on=True):
-        """Opt in to (or out of) the split-precision kernels for the layers that have one: f32 operands carried
-        as f16 hi + f16 lo/2048, three f16 MFMAs per product sum, f32 accumulation (csrc/conv_rl16.hip).  Default
-        off = exact-f32 matrix-core arithmetic everywhere (env ADK_SPLIT16=1 flips the default)."""
+        """Split-precision kernels for the layers that have one (default on; ADK_SPLIT16=0 flips it): f32 operands carried
+        as f16 hi + f16 lo/2048, three f16 MFMAs per product sum, f32 accumulation (csrc/conv_rl16.hip).  Off =
+        exact-f32 matrix-core arithmetic everywhere."""
         if bool(on) != self.split16:
             self.split16 = bool(on)
             self._drop_programs()
@@ -110,11 +125,30 @@ class _StreamBase:
     def _all_programs(self):
         return list(self._programs().values())
 
-    def _new_program(self, builder):
-        pr = program.HipProgram(builder, self.num_streams, self.max_frames, self._dev(), graph=self.graph and not self.offline)
+    def _new_program(self, make_builder):
+        """make_builder(split16) -> program.Builder.  The program is lowered in this object's arithmetic and remembers how to
+        lower its exact-f32 twin (HipProgram.demote)."""
+        pr = program.HipProgram(make_builder(self.split16), self.num_streams, self.max_frames, self._dev(), graph=self.graph and not self.offline,
+                                twin=(lambda: make_builder(False)) if self.split16 else None)
         if self.workgroups:
             pr.set_workgroups(self.workgroups)
         return pr
+
+    def _step(self, prog, frames, ext):
+        """One program step; with `guard`, checked and -- for a split-f16 range overflow -- repeated on the exact-f32 twin."""
+        prog.step(frames, ext)
+        if not self.guard:
+            return
+        fl = prog.flags()
+        if fl & native.FLAG_F16_OVERFLOW and prog.split16 and prog.twin_builder is not None and not prog.offline:
+            import warnings
+            prog.rewind(frames)
+            prog.demote()
+            prog.step(frames, ext)
+            fl = (fl & ~native.FLAG_F16_OVERFLOW) | prog.flags()
+            warnings.warn(f"{type(self).__name__}: an operand left the f16 range (|v| > 65504) in a split-f16 conv; the step was repeated with "
+                          "the exact-f32 kernels and this program continues on them", RuntimeWarning, stacklevel=3)
+        native.raise_for_flags(fl, type(self).__name__)
 
     def set_offline(self, offline=True):
         """offline=True lowers the NON-streaming Generator.forward used by the file-level drivers
@@ -202,7 +236,7 @@ class _StreamBase:
         B = self.num_streams
         if frames <= self.max_frames:
             out = torch.empty(B, frames * rows_out_per_frame, ch_out, dtype=torch.float32, device=src.device)
-            prog.step(frames, (src, out))
+            self._step(prog, frames, (src, out))
             return out
         out = torch.empty(B, frames * rows_out_per_frame, ch_out, dtype=torch.float32, device=src.device)
         f0 = 0
@@ -210,7 +244,7 @@ class _StreamBase:
             f = min(self.max_frames, frames - f0)
             s = src[:, f0 * rows_in_per_frame:(f0 + f) * rows_in_per_frame].contiguous()
             o = torch.empty(B, f * rows_out_per_frame, ch_out, dtype=torch.float32, device=src.device)
-            prog.step(f, (s, o))
+            self._step(prog, f, (s, o))
             out[:, f0 * rows_out_per_frame:(f0 + f) * rows_out_per_frame] = o
             f0 += f
         return out
@@ -257,12 +291,12 @@ class AutoEncoderStreamGenerator(_StreamBase):
     # ---- lazily built device state ----
     def _encoder(self):
         if self._enc is None:
-            self._enc = self._new_program(program.build_encoder(self._sd, self.params, self.split16))
+            self._enc = self._new_program(lambda s16: program.build_encoder(self._sd, self.params, s16))
         return self._enc
 
     def _decoder(self):
         if self._dec is None:
-            self._dec = self._new_program(program.build_sym_decoder(self._sd, self.params, self.offline, self.split16))
+            self._dec = self._new_program(lambda s16: program.build_sym_decoder(self._sd, self.params, self.offline, s16))
         return self._dec
 
     def _quantizer(self):
@@ -456,14 +490,14 @@ class HiFiGANStreamGenerator(_StreamBase):
         if self.stages != 1:
             raise native.NativeError("this generator is lowered in several stages: use _decoder_stages()")
         if self._dec is None:
-            self._dec = self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16))
+            self._dec = self._new_program(lambda s16: program.build_hifigan(self._sd, self.params, self.offline, s16))
         return self._dec
 
     def _decoder_stages(self):
         if self.stages == 1:
             return [self._decoder()]
         if self._dec_parts is None:
-            self._dec_parts = [self._new_program(program.build_hifigan(self._sd, self.params, self.offline, self.split16, part, self.cuts))
+            self._dec_parts = [self._new_program(lambda s16, part=part: program.build_hifigan(self._sd, self.params, self.offline, s16, part, self.cuts))
                                for part in range(self.stages)]
         return self._dec_parts
 

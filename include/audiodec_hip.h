@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 9
+#define ADK_ABI_VERSION 10
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -254,6 +254,16 @@ void adk_program_destroy(adk_program* p);
 int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream);
 /* reset_buffer(): zero all history (AudioDec.py:250-256, HiFiGAN.py:298-305) */
 int adk_program_reset(adk_program* p, void* stream);
+/* The launches of a program report device-side failures to a sticky word of the PROGRAM (same bits as adk_debug_flags, which
+ * also collects the words of all live programs).  adk_program_flags waits for `stream`, returns the word and clears it (one
+ * atomic exchange on the device): the caller that steps a program synchronously learns whether THIS step of THIS program
+ * failed, whatever other programs run on other host threads / HIP streams.  Bit 3 (an operand of a split-f16 kernel left the
+ * f16 range) is recoverable: a step only READS the history rows earlier steps left in the rings and WRITES this step's rows,
+ * so adk_program_rewind(p, frames) -- cursors back by the `frames` hops of the step just taken -- followed by the same step
+ * on a program lowered with the exact-f32 kernels over the same arena layout (copy the arena and the cursors across) repeats
+ * it exactly; audiodec_amd/stream_generator.py does that automatically for synchronous callers ("guard"). */
+int adk_program_flags(adk_program* p, void* stream, int32_t* out);
+int adk_program_rewind(adk_program* p, int32_t frames);
 /* How many persistent workgroups the stream-K conv launches of this program use (multiple of 8; 0 = default = the whole
  * chip, 2 per CU).  A caller that runs several programs CONCURRENTLY on different HIP streams (software pipeline over
  * batches, bench.py) gives each a share: at 3 concurrent programs 256 measured best (210 k vs 189 k frames/s). */
