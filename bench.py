@@ -29,10 +29,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak; a split-f16 product sum issues 3 of them
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_MARKER_N = 7654321                         # --pmc-markers: element count of the marker launches
-PMC_TRAFFIC_FILE = "r2_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench (tools/run_r2k.sh)
-PMC_TRAFFIC_SCRIPT = "tools/run_r3p.sh"
-PMC_TRAFFIC_COMMIT = "8c9de12"                 # the commit those passes were taken at
-
+PMC_TRAFFIC_FILE = "r3_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, pipelined schedule (tools/profile_round.sh)
+STEADY_STATS_FILE = "r3_kernel_stats_steady.csv"   # rocprofv3 --kernel-trace over the timed steps of the same schedule (tools/trace_summary.py)
+PMC_TRAFFIC_SCRIPT = "tools/profile_round.sh"
 
 def build_audiodec(root, device, streams, max_frames, sd_bcast=False):
     from audiodec_amd import synth
@@ -158,27 +157,78 @@ def op_profile(ad, xs, streams, n_steps, fps=1):
     return rows
 
 
-def pmc_traffic(dom, split16):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads, + WRITE_SIZE), averaged over ALL its launches between the
-    two --pmc-markers of those passes (= the timed steps of this same bench at 256 streams; tools/pmc_summary.py).
-    PMC counters cannot be collected from inside this process; None when the file is absent."""
-    import csv
+def _rocprof_name(dom):
+    """bench / describe_op kernel name -> substring(s) of the demangled kernel name in the rocprofv3 CSVs."""
     import re
-    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
     m = re.match(r"conv_sk(16)?<(\d+)x(\d+)>", dom)
-    if not os.path.exists(path) or not m or not split16:
-        return None
-    cfg = {"64x64": "<2, 2, 1,", "128x64": "<4, 1, 2,", "32x128": "<1, 4, 1,"}.get(f"{m.group(2)}x{m.group(3)}")
-    if cfg is None:
-        return None
+    if m:
+        cfg = {"64x64": "<2, 2, 1,", "128x64": "<4, 1, 2,", "32x128": "<1, 4, 1,"}.get(f"{m.group(2)}x{m.group(3)}")
+        return ("conv_sk_kernel" + cfg, "true" if m.group(1) else "false") if cfg else None
+    m = re.match(r"conv_rb16<(\d+)>", dom)
+    if m:
+        return (f"conv_rb16_kernel<{m.group(1)},",)
+    m = re.match(r"conv_rl16(_unit)?<(\d+)>", dom)
+    if m:
+        return (f"conv_rl16_kernel<{m.group(2)},",)
+    m = re.match(r"conv_up16<(\d+)>", dom)
+    if m:
+        return ("conv_up16_kernel<",)
+    return None
+
+
+def _profile_csv(name):
+    """(rows, header comments) of a committed profile CSV, or (None, {})."""
+    import csv
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, {}
+    lines = open(path).read().splitlines()
+    meta = {}
+    for l in lines:
+        if l.startswith("# ") and ":" in l:
+            k, v = l[2:].split(":", 1)
+            meta[k.strip()] = v.strip()
+    return list(csv.DictReader(l for l in lines if not l.startswith("#"))), meta
+
+
+def _digest_now():
+    import __graft_entry__ as g
+    return g.kernel_source_digest()[:16]
+
+
+def pmc_traffic(dom):
+    """HBM-side bytes per launch of kernel `dom` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for 16 B/lane streaming reads, + WRITE_SIZE), launch-weighted mean over ALL its launches between the two
+    --pmc-markers of those passes (= the timed steps of this same bench in the pipelined schedule; tools/pmc_summary.py).  PMC counters
+    cannot be collected from inside this process.  Returns (bytes or None, stale): stale = the kernels were rebuilt from other
+    sources since the capture (the file carries the source digest of its build)."""
+    rows, meta = _profile_csv(PMC_TRAFFIC_FILE)
+    sub = _rocprof_name(dom)
+    if rows is None or sub is None:
+        return None, None
     num = den = 0.0
-    for r in csv.DictReader(l for l in open(path) if not l.startswith("#")):
-        if "conv_sk_kernel" + cfg in r["kernel"] and "true" in r["kernel"]:
+    for r in rows:
+        if all(t in r["kernel"] for t in sub):
             n = float(r["launches"])
             num += n * (float(r["FETCH_KB_x2_corrected"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
             den += n
-    return round(num / den) if den else None
+    stale = meta.get("source_digest", "").split()[0:1] != [_digest_now()]
+    return (round(num / den) if den else None), stale
+
+
+def rocprof_duration(dom):
+    """Average duration (us) of kernel `dom` over the timed steps of the pipelined schedule, from the committed rocprofv3 kernel trace
+    (profiles/STEADY_STATS_FILE; the dispatch's own start/end, no launch gap, no event record), and whether that capture is stale."""
+    rows, meta = _profile_csv(STEADY_STATS_FILE)
+    sub = _rocprof_name(dom)
+    if rows is None or sub is None:
+        return None, None
+    num = den = 0.0
+    for r in rows:
+        if all(t in r["kernel"] for t in sub):
+            num += float(r["total_us"]); den += float(r["launches"])
+    stale = meta.get("source_digest", "").split()[0:1] != [_digest_now()]
+    return (round(num / den, 2) if den else None), stale
 
 
 FUSED = "(fused into the previous op)"
@@ -218,6 +268,14 @@ def mean_launch_bytes(launches, dom):
 
 def roofline_from(rows, streams, fps=1, split16=False):
     launches = launches_of(rows, streams, fps)
+    # What a per-op HIP-event pair costs by itself: the ops a launch swallowed ("fused into the previous op") are bracketed by two
+    # event records with NO kernel in between, so their "duration" is the overhead every per-op figure carries (~4.7 us).  It is
+    # measured here, in the run, and subtracted: avg_launch_us is the kernel, avg_launch_us_with_event what the events said.
+    gaps = [r["ms"] for r in rows if r["kernel"] == FUSED]
+    ev_ms = float(np.median(gaps)) if gaps else 0.0
+    for L in launches:
+        L["ms_raw"] = L["ms"]
+        L["ms"] = max(L["ms"] - ev_ms * len(L["ops"]), 0.25 * L["ms"])
     by = {}
     for r in launches:
         d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
@@ -228,15 +286,24 @@ def roofline_from(rows, streams, fps=1, split16=False):
     # algorithmic (f32-equivalent) flops against the matrix-core peak of the instruction the kernel issues: the exact-f32
     # MFMA, or -- for the split-f16 kernels -- the dense f16 MFMA peak divided by the 3 instructions per product sum
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
+    traffic, stale = pmc_traffic(dom)
+    rp_us, rp_stale = rocprof_duration(dom)
+    raw_ms = sum(L["ms_raw"] for L in launches if L["kernel"] == dom)
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": pmc_traffic(dom, split16),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_stale": stale,
             "algorithmic_bytes_per_launch": mean_launch_bytes(launches, dom),
             "traffic_note": "both are means per launch over all launches of this kernel in the timed steps: traffic = FETCH_SIZE x2 + "
-                            f"WRITE_SIZE from the committed PMC passes over this bench (profiles/{PMC_TRAFFIC_FILE}, captured at commit "
-                            f"{PMC_TRAFFIC_COMMIT} with {PMC_TRAFFIC_SCRIPT}, steady-state launches picked out by --pmc-markers; PMC counters cannot "
-                            "be read from inside the bench process), not collected live; algorithmic = input rows incl. history + weights + "
-                            "outputs (+ residual / state rows), once each",
+                            f"WRITE_SIZE from the committed PMC passes over this bench in the SAME pipelined schedule (profiles/{PMC_TRAFFIC_FILE}, "
+                            f"{PMC_TRAFFIC_SCRIPT}, steady-state launches picked out by --pmc-markers; PMC counters cannot be read from inside the "
+                            "bench process), not collected live -- traffic_stale says whether the kernels were rebuilt from other sources since; "
+                            "algorithmic = input rows incl. history + weights + outputs (+ residual / state rows), once each",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
+            "avg_launch_us_with_event": round(1e3 * raw_ms / d["launches"], 2), "event_pair_overhead_us": round(1e3 * ev_ms, 2),
+            "avg_launch_us_rocprof": rp_us, "rocprof_stale": rp_stale,
+            "duration_note": "avg_launch_us = per-op HIP-event time on the launch stream minus the cost of the event pair itself, which this run "
+                             "measures on the ops that ran inside another op's launch (two records, no kernel in between); avg_launch_us_rocprof = the "
+                             f"same kernel's dispatch duration in the committed rocprofv3 kernel trace of the timed steps (profiles/{STEADY_STATS_FILE}; "
+                             "there the three programs run concurrently, so a kernel shares the chip -- it is not expected to be shorter)",
             "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3),
             "launches_per_step_all_kernels": len(launches)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)

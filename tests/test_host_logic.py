@@ -262,8 +262,21 @@ def test_pmc_summary_keeps_only_the_marked_region(tmp_path):
     out = tmp_path / "out.csv"
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(tmp_path), str(out)], stdout=subprocess.DEVNULL)
     lines = out.read_text().splitlines()
-    assert lines[0].startswith("# region: launches between the two")
-    assert lines[2] == '"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,2,200,400,20'
+    assert lines[0].startswith("# source_digest: ") and len(lines[0].split()[2]) == 16     # the build the capture belongs to (bench.py: traffic_stale)
+    assert lines[1].startswith("# region: launches between the two")
+    assert lines[3] == '"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,2,200,400,20'
+    # tools/trace_summary.py: the same marker logic for a rocprofv3 --kernel-trace CSV (steady-state kernel durations)
+    th = '"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"\n'
+    def trow(i, grid, name, t0, t1):
+        return f'"KERNEL_DISPATCH","Agent 2",1,0,1,{i},1,"{name}",{i},{t0},{t1},1024,0,64,0,32,256,1,1,{grid},1,1\n'
+    td = tmp_path / "trace"
+    td.mkdir()
+    (td / "p_kernel_trace.csv").write_text(th + trow(1, 122880, k, 0, 90000) + trow(2, 7654400, ar, 100000, 100100) + trow(3, 122880, k, 200000, 210000)
+                                           + trow(4, 122880, k, 220000, 250000) + trow(5, 7654400, ar, 300000, 300100) + trow(6, 122880, k, 400000, 490000))
+    out2 = tmp_path / "steady.csv"
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "trace_summary.py"), str(td), str(out2), "2"], stdout=subprocess.DEVNULL)
+    body = [l for l in out2.read_text().splitlines() if not l.startswith("#")]
+    assert body[1].startswith('"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,256,2,1.00,20.00,10.00,30.00,40.0,100.00,'), body[1]
 
 
 def test_bench_gpus_n_launches_its_own_ranks_or_fails_loudly():

@@ -32,6 +32,13 @@ def load(d, counter):
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     return acc
 
+def source_digest():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as g
+    return g.kernel_source_digest()[:16]
+
+
 def main():
     root, out = sys.argv[1], sys.argv[2]
     fd = [d for d in glob.glob(os.path.join(root, "*FETCH_SIZE*")) if os.path.isdir(d)]
@@ -48,6 +55,7 @@ def main():
         name = k[0].replace("void adk::", "").split("(adk::")[0]
         rows.append((name, k[1], max(fa[1], wa[1]), round(fk), round(2 * fk), round(wk)))
     with open(out, "w") as fh:
+        fh.write("# source_digest: %s   (sha256 of audiodec_amd/csrc/*.hip + headers at capture: bench.py marks roofline.traffic stale when the build differs)\n" % source_digest())
         fh.write("# region: %s\n" % ("launches between the two bench.py --pmc-markers (the timed steps)" if MARKERS[0] == MARKERS[1] and MARKERS[1]
                                      else "ALL launches of the passes (markers not found in every pass)"))
         fh.write("kernel,grid_threads,launches,FETCH_SIZE_KB_avg,FETCH_KB_x2_corrected,WRITE_SIZE_KB_avg\n")
