@@ -76,6 +76,7 @@ static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling stre
 static int g_use_chain = -1;    // ADK_CHAIN=0: residual chains run op by op (A/B against the per-op kernels)
 static int g_chain_max_c = -1;  // adk_set_option("chain_max_channels") / ADK_CHAIN_MAXC
 static int g_chain_min_c = -1;  // adk_set_option("chain_min_channels") / ADK_CHAIN_MINC
+static int g_chain_min_blocks = -1;   // adk_set_option("chain_min_blocks") / ADK_CHAIN_MIN_BLOCKS: fewer (stream, group) workgroups -> per-op launches
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
@@ -86,6 +87,9 @@ static void read_env() {
     if (g_use_chain < 0) { const char* e = getenv("ADK_CHAIN"); g_use_chain = e ? atoi(e) : 1; }
     if (g_chain_max_c < 0) { const char* e = getenv("ADK_CHAIN_MAXC"); g_chain_max_c = e ? atoi(e) : 128; }
     if (g_chain_min_c < 0) { const char* e = getenv("ADK_CHAIN_MINC"); g_chain_min_c = e ? atoi(e) : 0; }
+    // measured crossover (tools/chain_crossover.py, profiles/r3_chain_crossover.log): below ~160 (stream, group) pairs the per-op launches,
+    // which spread one stream's time tiles over many CUs, are faster than one workgroup per pair walking the whole chain
+    if (g_chain_min_blocks < 0) { const char* e = getenv("ADK_CHAIN_MIN_BLOCKS"); g_chain_min_blocks = e ? atoi(e) : 160; }
 }
 
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
@@ -153,6 +157,7 @@ extern "C" int adk_set_option(const char* name, int32_t value) {
     read_env();
     if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
+    if (!strcmp(name, "chain_min_blocks")) { g_chain_min_blocks = value < 0 ? 0 : value; return ADK_OK; }
     return fail(ADK_ERR_ARG, std::string("adk_set_option: unknown option ") + name);
 }
 
@@ -446,6 +451,7 @@ static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext
     const int n = p->ops[i].chain;
     if (!g_use_chain || !g_use_rl || n < 2 || n > kMaxChain || i + n > (int)p->ops.size()) return false;
     if (p->ops[i].conv.cin_g > g_chain_max_c || p->ops[i].conv.cin_g < g_chain_min_c) return false;
+    if ((long long)p->batch * p->ops[i].conv.groups < g_chain_min_blocks) return false;
     for (int k = 0; k < n; ++k) {
         const adk_op_desc& o = p->ops[i + k];
         if (o.kind != ADK_OP_CONV || o.impl != ADK_IMPL_SPLIT16) return false;

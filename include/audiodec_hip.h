@@ -72,6 +72,9 @@ int adk_set_conv_cfg(int32_t cfg);
  *                         (default 128 = every chain the kernel takes; 64: not the 128-channel ones; 0: never -- the ops of a
  *                         chain are then launched one by one, as with ADK_CHAIN=0).  State rings are compatible either way:
  *                         the value may change between two steps of a running program.
+ *   "chain_min_channels"  ... and from this many channels per group (default 0)
+ *   "chain_min_blocks"    ... and only for launches of at least this many (stream, group) pairs (default 160, the measured
+ *                         crossover: below it the per-op launches, which spread a stream's time tiles over many CUs, are faster)
  * ADK_ERR_ARG for an unknown name. */
 int adk_set_option(const char* name, int32_t value);
 /* Introspection of the stream-K launch schedule (pure host logic, no device needed; used by the CPU tests): a matrix-core conv

@@ -356,6 +356,7 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
     hop = HOP
     old = program.FUSE_RES_UNITS, program.FUSE_CHAINS
     try:
+        native.set_option("chain_min_blocks", 0)             # (by default only launches of >= 160 workgroups run as chains)
         native.set_option("chain_max_channels", 64)          # the warm-up of the fused model runs 28 steps: keep it exact too
         program.FUSE_RES_UNITS, program.FUSE_CHAINS = True, True
         ad_f = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
@@ -411,4 +412,5 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
                     assert float((yf - yu).abs().max()) < 2e-5, (i, float((yf - yu).abs().max()))
     finally:
         native.set_option("chain_max_channels", 128)
+        native.set_option("chain_min_blocks", 160)
     assert native.device_flags() == 0

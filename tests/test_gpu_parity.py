@@ -326,11 +326,17 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
     model, seed, n = str(g["model"]), int(g["seed"]), int(g["n_streams"])
     chunks = golden_chunks(g)
     audio = np.stack([synth.synth_audio(seed, s, sum(chunks)) for s in range(n)])
-    ad = load_audiodec(ckpt_root, model, seed, n, max_frames, split16)
-    if split16:                                              # the opt-in kernels really are in the programs
-        kinds = [ad.decoder._decoder().describe_op(i, 1) for i in range(ad.decoder._decoder().n_ops)]
-        assert any(k.startswith("conv_rl16") or k.startswith("conv_sk16") for k in kinds), kinds
-    z, idx, zq, y = run_hip(ad, audio, chunks)
+    from audiodec_amd import native
+    native.set_option("chain_min_blocks", 0 if split16 else 160)     # split16: the residual chains run as one launch even for these 1-2 streams
+    try:
+        ad = load_audiodec(ckpt_root, model, seed, n, max_frames, split16)
+        if split16:                                              # the split kernels really are in the programs
+            kinds = [ad.decoder._decoder().describe_op(i, 1) for i in range(ad.decoder._decoder().n_ops)]
+            assert any(k.startswith("conv_rl16") or k.startswith("conv_sk16") for k in kinds), kinds
+            assert any(k.startswith("conv_rb16") for k in kinds), kinds
+        z, idx, zq, y = run_hip(ad, audio, chunks)
+    finally:
+        native.set_option("chain_min_blocks", 160)
     assert z.shape == g["z"].shape and y.shape == g["y"].shape and idx.shape == g["idx"].shape
     assert np.abs(z - g["z"]).max() < WAVE_TOL
     explain_flips(idx, g["idx"], g["margin"], name)
