@@ -333,7 +333,7 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
         if split16:                                              # the split kernels really are in the programs
             kinds = [ad.decoder._decoder().describe_op(i, 1) for i in range(ad.decoder._decoder().n_ops)]
             assert any(k.startswith("conv_rl16") or k.startswith("conv_sk16") for k in kinds), kinds
-            assert any(k.startswith("conv_rb16") for k in kinds), kinds
+            assert "noaddl" in model or any(k.startswith("conv_rb16") for k in kinds), kinds     # (x + convs1(act(x)) blocks have no chain)
         z, idx, zq, y = run_hip(ad, audio, chunks)
     finally:
         native.set_option("chain_min_blocks", 160)
