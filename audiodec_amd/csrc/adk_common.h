@@ -80,6 +80,9 @@ int launch_conv_rl16_fused(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s
 bool conv_rb16_fusable(const ConvArgs* c, int n);
 int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s);   // ADK_ERR_STATE: not fusable for this call
 const char* conv_rb16_name(const ConvArgs* c, int n);
+// conv_out (1x1, 192 -> 64) + activation + the last up-sampler's transposed conv as one streaming launch (conv_ou16.hip)
+bool conv_ou16_fusable(const ConvArgs& a1, const ConvArgs& a2);
+int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s);     // ADK_ERR_STATE: not fusable for this call
 bool conv_up16_supported(const ConvArgs& a);        // streaming kernel of the last up-sampling stage (64 -> s*Cout <= 96 rows, 2 taps)
 int launch_conv_up16(const ConvArgs& a, hipStream_t s);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)

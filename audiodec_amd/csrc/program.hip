@@ -433,15 +433,23 @@ static int op_conv_args(adk_program* p, int i, int frames, void* const* ext, Con
     return rc;
 }
 
-// Can ops i, i+1 (a residual unit: conv -> 1x1 + residual) run as one launch for a `frames`-hop step?
-static bool op_pair_fusable(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a1, ConvArgs& a2) {
+// Can ops i, i+1 run as one launch for a `frames`-hop step?  0: no; 1: a residual unit (conv -> 1x1 + residual: conv_rl16 FUSE);
+// 2: the 1x1 conv_out of a vocoder stage + the next stage's activation and transposed conv (conv_ou16)
+static int g_use_ou = -1;       // ADK_CONV_OU16=0: conv_out and the up-sampler stay two launches (A/B)
+static int op_pair_kind(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a1, ConvArgs& a2) {
     read_env();
-    if (i + 1 >= (int)p->ops.size()) return false;
+    if (g_use_ou < 0) { const char* e = getenv("ADK_CONV_OU16"); g_use_ou = e ? atoi(e) : 1; }
+    if (i + 1 >= (int)p->ops.size()) return 0;
     const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
-    if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16 || o2.impl != ADK_IMPL_SPLIT16) return false;
-    if (o2.in_ring != o1.out_ring || p->rings[o1.out_ring].external >= 0 || !g_use_rl) return false;
-    if (op_conv_args(p, i, frames, ext, a1) != ADK_OK || op_conv_args(p, i + 1, frames, ext, a2) != ADK_OK) return false;
-    return conv_rl16_fusable(a1, a2);
+    if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16 || o2.impl != ADK_IMPL_SPLIT16) return 0;
+    if (o2.in_ring != o1.out_ring || p->rings[o1.out_ring].external >= 0) return 0;
+    if (op_conv_args(p, i, frames, ext, a1) != ADK_OK || op_conv_args(p, i + 1, frames, ext, a2) != ADK_OK) return 0;
+    if (g_use_rl && conv_rl16_fusable(a1, a2)) return 1;
+    if (g_use_ou && g_use_up && conv_ou16_fusable(a1, a2)) return 2;
+    return 0;
+}
+static bool op_pair_fusable(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a1, ConvArgs& a2) {
+    return op_pair_kind(p, i, frames, ext, a1, a2) == 1;
 }
 
 // Can ops [i, i + n) (a residual chain, adk_op_desc.chain) run as one launch for a `frames`-hop step?  Fills c[] / keep[].
@@ -479,10 +487,13 @@ static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream
                 if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (chain): " + g_err; return rc; }
             }
         }
-        if (consumed && max_consume >= 2 && o.fuse_next && op_pair_fusable(p, i, frames, ext, a, a2)) {
-            rc = launch_conv_rl16_fused(a, a2, s);
-            if (rc == ADK_OK) { *consumed = 2; return ADK_OK; }
-            if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (fused): " + g_err; return rc; }
+        if (consumed && max_consume >= 2 && o.fuse_next) {
+            const int kind = op_pair_kind(p, i, frames, ext, a, a2);
+            if (kind) {
+                rc = kind == 1 ? launch_conv_rl16_fused(a, a2, s) : launch_conv_ou16(a, a2, s);
+                if (rc == ADK_OK) { *consumed = 2; return ADK_OK; }
+                if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (fused): " + g_err; return rc; }
+            }
         }
         rc = op_conv_args(p, i, frames, ext, a);
         if (rc == ADK_OK) rc = run_conv(a, o.impl, s, p->ws);
@@ -671,8 +682,8 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         for (int h = op; h >= 0 && h > op - kMaxChain; --h)
             if (p->ops[h].kind == ADK_OP_CONV && p->ops[h].chain >= 2 && h + p->ops[h].chain > op) { head = h; break; }
         if (head >= 0 && op_chain_fusable(p, head, frames, ext, c, keep)) name = head == op ? conv_rb16_name(c, p->ops[head].chain) : "(fused into the previous op)";
-        else if (o.fuse_next && op_pair_fusable(p, op, frames, ext, f1, f2)) name = f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>";
-        else if (op > 0 && p->ops[op - 1].fuse_next && op_pair_fusable(p, op - 1, frames, ext, f1, f2)) name = "(fused into the previous op)";
+        else if (o.fuse_next && op_pair_kind(p, op, frames, ext, f1, f2)) name = op_pair_kind(p, op, frames, ext, f1, f2) == 2 ? "conv_ou16<192>" : (f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>");
+        else if (op > 0 && p->ops[op - 1].fuse_next && op_pair_kind(p, op - 1, frames, ext, f1, f2)) name = "(fused into the previous op)";
     }
     snprintf(buf, n, "%s", name.c_str());
     return ADK_OK;

@@ -391,7 +391,8 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
         rate *= s
         x0 = b.ring(c, 0, rate)                                 # block input, un-repeated
         b.conv(f"upsamples.{i}", cur, x0, act, slope)           # upsamples[i].inference(act(c))
-        cur = b.ring(c, 0, rate, external=1 if (part is not None and last < n_up and i == last - 1) else -1)
+        cur_internal = not (part is not None and last < n_up and i == last - 1)
+        cur = b.ring(c, 0, rate, external=-1 if cur_internal else 1)
         if multigroup:
             # MultiGroupConv1d.inference (multi_fusion.py:133-141): x.repeat(1, groups, 1) is never
             # materialised -- the first conv and the first residual read the same C channels per group
@@ -409,7 +410,10 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
                     nx = b.ring(c * groups, 0, rate)
                     b.conv(f"blocks.{i}.convs1.{j}", x, nx, act, slope, in_group_stride=gs_in, res_ring=x, res_group_stride=gs_res)
                 x, gs_in, gs_res = nx, None, None
-            b.conv(f"blocks.{i}.conv_out", x, cur)
+            # the 1x1 conv_out feeds only the next stage's activation + transposed conv: the runner may run the two as one
+            # streaming launch (csrc/conv_ou16.hip; the 64-channel tensor between them then never exists in memory)
+            nxt_is_up = i + 1 < last and cur_internal and not offline and FUSE_RES_UNITS
+            b.conv(f"blocks.{i}.conv_out", x, cur, fuse_next=nxt_is_up)
         else:
             # MultiReceptiveField.inference (multi_fusion.py:73-79): mean of the residual blocks, all fed by x0
             outs = []

@@ -306,19 +306,32 @@ def roofline_from(rows, streams, fps=1, split16=False):
                              "there the three programs run concurrently, so a kernel shares the chip -- it is not expected to be shorter)",
             "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3),
             "launches_per_step_all_kernels": len(launches)}
-    # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler)
-    ct = [r for r in rows if r["name"] == "upsamples.3"]
+    # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler) -- since round 3 the launch
+    # that contains it also runs the 1x1 conv_out (192 -> 64) in front of it (conv_ou16): bytes and time are those of THAT launch
+    ct = [L for L in launches if any(q["name"] == "upsamples.3" for q in L["ops"])]
     roof_ct = None
     if ct:
-        r = ct[0]; c = r["op"].conv
-        t_in = r["op"].rate_out * fps
+        L = ct[0]
+        up = [q for q in L["ops"] if q["name"] == "upsamples.3"][0]
+        c = up["op"].conv
+        t_in = up["op"].rate_out * fps
         cin, cout, s = c.cin_g, c.cout_real, c.up
-        bytes_alg = 4.0 * (cin * (t_in + 1) + cout * t_in * s) * streams + 4.0 * cin * cout * 2 * s
-        gbs = bytes_alg / (r["ms"] * 1e-3) / 1e9
-        roof_ct = {"kernel": r["kernel"] + " upsamples.3 (LeakyReLU+ConvTranspose1d 64->32 s3 +bias)", "bound": "hbm",
-                   "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                   "traffic": None, "avg_launch_us": round(1e3 * r["ms"], 2), "bytes_per_launch": bytes_alg,
-                   "fp32_tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2)}
+        fused = len(L["ops"]) > 1
+        if fused:
+            c1 = L["ops"][0]["op"].conv                      # the 1x1 conv: reads cin1 channels per step, the 64-channel tensor stays on chip
+            bytes_alg = 4.0 * (c1.cin_g * t_in + cin + cout * t_in * s) * streams + 4.0 * (c1.cin_g * c1.cout_g + cin * cout * 2 * s)
+            what = f"{L['kernel']} blocks.2.conv_out (1x1 {c1.cin_g}->{c1.cout_g}) + LeakyReLU + upsamples.3 (ConvTranspose1d {cin}->{cout} s{s} + bias), one launch"
+        else:
+            bytes_alg = 4.0 * (cin * (t_in + 1) + cout * t_in * s) * streams + 4.0 * cin * cout * 2 * s
+            what = L["kernel"] + " upsamples.3 (LeakyReLU+ConvTranspose1d 64->32 s3 +bias)"
+        gbs = bytes_alg / (L["ms"] * 1e-3) / 1e9
+        rp_us, rp_stale = rocprof_duration(L["kernel"])
+        roof_ct = {"kernel": what, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "traffic": pmc_traffic(L["kernel"])[0], "avg_launch_us": round(1e3 * L["ms"], 2), "avg_launch_us_with_event": round(1e3 * L["ms_raw"], 2),
+                   "avg_launch_us_rocprof": rp_us, "rocprof_stale": rp_stale, "bytes_per_launch": bytes_alg, "fused_with_conv_out": fused,
+                   "fp32_tflops": round(L["flops"] / (L["ms"] * 1e-3) / 1e12, 2),
+                   "how": "HIP events around the launch in the serial per-op profile (one HIP stream, nothing else on the chip) minus the measured cost of "
+                          "the event pair; avg_launch_us_rocprof is the dispatch duration inside the concurrent three-stream schedule"}
     kernels = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0} for k, v in by.items()}
     return roof, roof_ct, kernels
@@ -777,20 +790,13 @@ def main():
                                     f"{(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0:.2f}\n")
                 roof, roof_ct, kernels = roofline_from(rows, B, FPS, args.precision == "split16")
                 if roof_ct is not None:
-                    # the named kernel by itself (back-to-back launches): this is the figure that compares with rocprofv3's
-                    # kernel duration; the in-pipeline per-op event time is kept next to it
+                    # the transposed conv of the named kernel BY ITSELF (conv_up16, 300 back-to-back launches): the figure of rounds 1-2, kept for
+                    # comparison with the fused launch above
                     us, kname = convtr_standalone(dev, sds[dec_tag], B, FPS, args.precision == "split16")
-                    gbs = roof_ct["bytes_per_launch"] / (us * 1e-6) / 1e9
-                    roof_ct["in_pipeline"] = {"avg_launch_us": roof_ct["avg_launch_us"], "achieved": roof_ct["achieved"], "frac": roof_ct["frac"],
-                                              "note": "HIP events around the op inside the serial per-op profile: includes the gap to the previous launch and the event record"}
-                    roof_ct.update({"kernel": kname + " upsamples.3 (LeakyReLU+ConvTranspose1d 64->32 s3 +bias)", "achieved": round(gbs, 1),
-                                    "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 2),
-                                    "how": "300 back-to-back launches of this layer alone (same weights, 256 streams x 100 input steps), HIP events on the launch stream",
-                                    "fp32_tflops": round(2.0 * 96 * 128 * 100 * FPS * B / (us * 1e-6) / 1e12, 2),
-                                    "note": "one frame per stream per launch is 16.5 MB: ~6.4 us of this launch are fixed (dispatch, one memory round trip, 72 MFMAs "
-                                            "per wave, store drain; a single stream takes 6.4 us), so 0.40 of the HBM roof (5.2 us) is out of reach at T = 1; "
-                                            "measured with tools/kbench: 2.0 TB/s (0.25) at 256 stream-frames per launch, 3.0 TB/s (0.38) at 1024 -- about 4 "
-                                            "frames per stream per launch at 256 streams, see profiles/README.md"})
+                    b_alone = 4.0 * (64 * (100 * FPS + 1) + 32 * 300 * FPS) * B + 4.0 * 64 * 32 * 6
+                    roof_ct["transposed_conv_alone"] = {"kernel": kname, "avg_launch_us": round(us, 2), "bytes_per_launch": b_alone,
+                                                        "achieved": round(b_alone / (us * 1e-6) / 1e9, 1), "frac": round(b_alone / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                        "how": "300 back-to-back launches of upsamples.3 alone (same weights, 256 streams x 100 input steps), HIP events inside the library"}
                 out["roofline"] = roof
                 out["roofline_convtr"] = roof_ct
                 out["kernels"] = kernels
