@@ -18,7 +18,24 @@
 #include "adk_common.h"
 #include <type_traits>
 
+#ifndef ADK_OU16_DBG
+#define ADK_OU16_DBG 0      // tuning builds only: 1 = per-workgroup wall-clock stamps (s_memrealtime, 100 MHz) of wave 0
+#endif
+
 namespace adk {
+
+#if ADK_OU16_DBG & 1
+// [workgroup 0..1023][stamp]: 0 entry, 1 loads + LDS-DMA issued, 2 first barrier passed (everything landed), 3 GEMM 1 done (72 MFMAs),
+// 4 c written to LDS + second barrier passed, 5 GEMM 2 MFMAs and stores issued (exit)
+__device__ unsigned long long g_ou_trace[1024 * 8];
+extern "C" int adk_debug_ou_trace(unsigned long long* out, int n) {
+    if (n > 1024 * 8) n = 1024 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ou_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#define OU_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (wave == 0 && blockIdx.x < 1024) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (lane == 0) g_ou_trace[blockIdx.x * 8 + (i)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define OU_STAMP(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -55,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
     const int t = wave * 32 + l31;
     const bool valid = t < T;
     const int tt = valid ? t : T - 1;                     // padded columns work on a copy of the last one; nothing of theirs is stored
+    OU_STAMP(0);
 
     const int w1_bytes = 2 * u.ks1p * 2048, w2_bytes = MT2 * OU_KS2 * 2048;
     unsigned char* w1l = lds;                              // [2 m-tiles][ks1p chunks][hi | lo][64 lanes][16 B]
@@ -89,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
         for (int i = 0; i < MT2 * OU_KS2 * 2048 / 4096; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(g2 + 4096 * i), (lptr_t)(l2 + 4096 * i), 16, 0, 0);
     }
+    OU_STAMP(1);
     __builtin_amdgcn_sched_barrier(0);
     if (tid < 32 * MT2) b2l[tid] = bias2_v;
     if (tid < OU_CM) b1l[tid] = bias1_v;
@@ -104,8 +123,13 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
         *reinterpret_cast<f16x4u*>(cbuf + 8 * tid) = hi;
         *reinterpret_cast<f16x4u*>(cbuf + 2 * OU_CM + 8 * tid) = lo;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA slices have landed (the other waves read them)
+    // this wave's activation loads and its slices of W1 have landed (the other waves read them); the MT2 * 4 LDS-DMA pieces of W2,
+    // issued last, may still be in flight: they are only needed after GEMM 1 (timeline: profiles/r3_ou16_timeline.md)
+    if constexpr (MT2 == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (MT2 == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __syncthreads();
+    OU_STAMP(2);
 
     bool bad = false;
     // ---- GEMM 1: c[m][t] = sum_k W1[m][k] x[k][t], 64 rows (two m-tiles) x this wave's 32 steps ----
@@ -134,6 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
                 ac[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh, ac[mt], 0, 0, 0);
             }
         }
+        OU_STAMP(3);
         // c (+ bias): the last step's row goes to the 64-channel ring (the next call's history); act(c), split, to the LDS buffer
         float* crow = nullptr;
         if (valid && t == T - 1) {
@@ -168,7 +193,9 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
                 }
             }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W2 has landed
     __syncthreads();
+    OU_STAMP(4);
 
     // ---- GEMM 2: the polyphase transposed conv; k = (tap j, channel), tap 0 = the older row c[t-1] = buffer row t, tap 1 = row t + 1 ----
     float* outb = a2.out + (size_t)b * a2.out_rows * a2.out_ch + a2.out_choff;
@@ -211,6 +238,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
             *reinterpret_cast<float4*>(outb + (size_t)r2 * a2.out_ch + (ml - ph * a2.cout_real)) = v;
         }
     }
+    OU_STAMP(5);
     if (bad) atomicOr(u.err, 8);
 }
 
