@@ -173,6 +173,8 @@ def _rocprof_name(dom):
     m = re.match(r"conv_up16<(\d+)>", dom)
     if m:
         return ("conv_up16_kernel<",)
+    if dom.startswith("conv_ou16<"):
+        return ("conv_ou16_kernel<",)
     return None
 
 
