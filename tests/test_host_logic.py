@@ -220,11 +220,11 @@ def test_extra_aliases_are_not_reference_names():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r2_bench_latest.json is one JSON line of bench.py on an MI355X: the keys the driver and the judge read are there, the
+    """profiles/r3_bench_latest.json is one JSON line of bench.py on an MI355X: the keys the driver and the judge read are there, the
     metric / unit are BASELINE.json's, `value` is consistent with `ms_per_step`, roofline.frac = achieved / peak."""
     import json
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    line = open(os.path.join(root, "profiles", "r2_bench_latest.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(root, "profiles", "r3_bench_latest.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -240,6 +240,11 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["self_check"]["ok"] is True and d["device_error_flags"] == 0
+    # round 3: the traffic / rocprof figures name the build they were profiled on, the event overhead is measured and subtracted
+    assert r["traffic_stale"] is False and r["rocprof_stale"] is False and 1.0 < r["event_pair_overhead_us"] < 10.0
+    assert r["avg_launch_us"] < r["avg_launch_us_with_event"] and r["launches_per_step_all_kernels"] <= 45
+    ct = d["roofline_convtr"]
+    assert ct["bound"] == "hbm" and ct["fused_with_conv_out"] is True and abs(ct["frac"] - ct["achieved"] / ct["peak"]) < 1e-3
 
 
 def test_pmc_summary_keeps_only_the_marked_region(tmp_path):
