@@ -63,6 +63,7 @@ EXPERIMENTS = {
     # NOT in the reference's exp/: the generator option no released config switches off (HiFiGANResidualBlock
     # use_additional_convs=False, modules/residual_block.py:93-106: x + convs1(act(x)) without the second conv), as v1- and
     # v0-shaped vocoders, so that the lowering of that branch has reference fixtures too (EXTRA_ALIASES below)
+    "autoencoder/test_stereo_symAD_vctk_48000_hop300": ("symAudioDec", 48000, dict(_ae(), input_channels=2, output_channels=2)),
     "vocoder/test_v1_noaddl_symAD_vctk_48000_hop300": (
         "HiFiGAN", 48000, _voc([11], 3, "stats/symAD_vctk_48000_hop300_clean.npy", use_additional_convs=False)),
     "vocoder/test_v0_noaddl_symAD_vctk_48000_hop300": (
@@ -108,6 +109,10 @@ _ALIASES = {
 # Model names that are NOT the reference's (its assign_model raises for them, and so does ours): test models for generator options
 # no released alias exercises.  configs.alias / checkpoint_paths / synth.write_model know them; assign_model does not.
 EXTRA_ALIASES = {
+    # a stereo codec (input_channels = output_channels = 2: AudioDec.py:229-231 folds any other channel count into the batch);
+    # no released checkpoint is stereo, the generator takes the parameters all the same
+    "test_stereo_sym": (48000, "autoencoder/test_stereo_symAD_vctk_48000_hop300", 200000,
+                        "autoencoder/test_stereo_symAD_vctk_48000_hop300", 700000),
     "test_v1_noaddl": (48000, "autoencoder/symAD_vctk_48000_hop300", 200000,
                        "vocoder/test_v1_noaddl_symAD_vctk_48000_hop300", 500000),
     "test_v0_noaddl": (48000, "autoencoder/symAD_vctk_48000_hop300", 200000,

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr int MT = C / 32;
     constexpr int NW = 4, NT = 64 * NW;
     constexpr int WM = NW / MT;                         // waves that share an m-tile (and its weight stream)
-    constexpr bool BIAS_LDS = C < 128;                 // bias of every conv staged in LDS (the 128-channel variant has no LDS to spare, but registers)
+    constexpr bool BIAS_LDS = C < 128 && !(C == 64 && SMAX == 2);    // bias of every conv staged in LDS -- unless the LDS is needed to the last KB for a second workgroup per CU
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
 
@@ -508,7 +508,8 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
     if (pl.hm > kRbMaxHist) return false;
     pl.rps = pl.hm + T;
-    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (pl.C < 128 ? (size_t)n * pl.C * 4 : 0);
+    const bool bias_lds = pl.C < 128 && !(pl.C == 64 && (pl.spw > 1 || pl.ntw > 2));        // (as BIAS_LDS of the instantiation rb_by_taps picks)
+    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0);
     if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 2 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
     pl.blocks = (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups;
     return pl.blocks <= 0x7fffffffLL;

@@ -265,9 +265,9 @@ class AutoEncoderStreamGenerator(_StreamBase):
             raise NotImplementedError(f"Model ({p['projector']}) is not supported!")
         if p["quantier"] != "residual_vq":
             raise NotImplementedError(f"Model ({p['quantier']}) is not supported!")
-        if p["input_channels"] != 1 or p["output_channels"] != 1:
-            raise NotImplementedError("only mono (input_channels = output_channels = 1) is lowered")
-        self.input_channels = p["input_channels"]
+        if p["input_channels"] < 1 or p["output_channels"] < 1:
+            raise ValueError("input_channels / output_channels must be positive")
+        self.input_channels, self.output_channels = p["input_channels"], p["output_channels"]
         self.hop = arch.hop_length(p)
         self.n_q, self.dim, self.size = p["codebook_num"], p["code_dim"], p["codebook_size"]
         self._enc = self._dec = None
@@ -350,8 +350,11 @@ class AutoEncoderStreamGenerator(_StreamBase):
             # one-shot call on a ragged length (demoFile.py:58): zero-pad to a hop multiple; every output
             # frame is exact by causality, only the state left behind differs
             x = torch.nn.functional.pad(x, (0, frames * self.hop - length))
-        src = x.reshape(x.shape[0], frames * self.hop, 1) if x.is_contiguous() else x.contiguous().reshape(x.shape[0], -1, 1)
-        z = self._run_chunks(self._encoder(), src, self.hop, 1, 1, self.dim, frames)
+        if self.input_channels == 1:
+            src = x.reshape(x.shape[0], frames * self.hop, 1) if x.is_contiguous() else x.contiguous().reshape(x.shape[0], -1, 1)
+        else:
+            src = x.transpose(1, 2).contiguous()               # channel-last rows (B, L, C): what the first conv's ring holds
+        z = self._run_chunks(self._encoder(), src, self.hop, self.input_channels, 1, self.dim, frames)
         return z.transpose(1, 2)
 
     def quantize(self, z):
@@ -418,7 +421,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
 
     def decode(self, zq):
         """zq (B, T, code_dim) -> y (B, out_channels, T*hop)  (AudioDec.py:246-247)."""
-        return _decode_common(self, self._decoder(), zq, self.dim, self.hop)
+        return _decode_common(self, self._decoder(), zq, self.dim, self.hop, self.output_channels)
 
     def reset_buffer(self):
         """Zero every state ring (AudioDec.py:250-256)."""
@@ -427,7 +430,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
                 pr.reset()
 
 
-def _decode_common(self, prog, zq, dim, hop):
+def _decode_common(self, prog, zq, dim, hop, out_ch=1):
     dev = self._dev()
     zq = zq.to(device=dev, dtype=torch.float32)
     if zq.dim() != 3 or zq.shape[2] != dim:
@@ -438,9 +441,9 @@ def _decode_common(self, prog, zq, dim, hop):
         raise ValueError(f"decode: got {zq.shape[0]} streams, this object carries {self.num_streams}")
     T = zq.shape[1]
     if T == 0:
-        return torch.empty(zq.shape[0], 1, 0, device=dev)
-    y = self._run_chunks(prog, zq.contiguous(), 1, dim, hop, 1, T)
-    return y.reshape(zq.shape[0], 1, T * hop)
+        return torch.empty(zq.shape[0], out_ch, 0, device=dev)
+    y = self._run_chunks(prog, zq.contiguous(), 1, dim, hop, out_ch, T)
+    return y.reshape(zq.shape[0], 1, T * hop) if out_ch == 1 else y.transpose(1, 2)
 
 
 class HiFiGANStreamGenerator(_StreamBase):

@@ -38,6 +38,7 @@ _CALIB_ALIAS = {
     "denoise/symAD_vctk_48000_hop300": "autoencoder/symAD_vctk_48000_hop300",
     "vocoder/AudioDec_v1_symAD_libritts_24000_hop300_clean": "vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean",
     "vocoder/AudioDec_v3_symADuniv_vctk_48000_hop300_clean": "vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean",
+    "autoencoder/test_stereo_symAD_vctk_48000_hop300": "autoencoder/symAD_vctk_48000_hop300",
     "vocoder/test_v1_noaddl_symAD_vctk_48000_hop300": "vocoder/AudioDec_v1_symAD_vctk_48000_hop300_clean",
     "vocoder/test_v0_noaddl_symAD_vctk_48000_hop300": "vocoder/AudioDec_v0_symAD_vctk_48000_hop300_clean",
 }

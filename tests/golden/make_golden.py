@@ -124,7 +124,9 @@ def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
     hop = ad.get_hop_length(configs.checkpoint_paths(model)[1])
     total = one_shot_len if one_shot_len is not None else sum(schedule) * hop
     chunks = [one_shot_len] if one_shot_len is not None else [c * hop for c in schedule]
-    audio = np.stack([synth.synth_audio(SEED, s, total) for s in range(n_streams)])
+    in_ch = configs.experiment(configs.alias(model)[1])[2].get("input_channels", 1)
+    # stream s = channels [s * in_ch, (s + 1) * in_ch) of the seeded audio (mono models: in_ch = 1)
+    audio = np.stack([synth.synth_audio(SEED, s, total) for s in range(n_streams * in_ch)]).reshape(n_streams, in_ch, total)
     zs, idxs, zqs, ys, margins = [], [], [], [], []
     # reference: one freshly loaded instance per stream (identical warm-up state)
     for s in range(n_streams):
@@ -133,7 +135,7 @@ def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
         pos = 0
         with torch.no_grad():
             for c in chunks:
-                x = torch.from_numpy(audio[s, pos:pos + c])[None, None, :]
+                x = torch.from_numpy(audio[s, :, pos:pos + c])[None]
                 pos += c
                 z = inst.tx_encoder.encode(x)
                 idx = inst.tx_encoder.quantize(z)
@@ -152,7 +154,7 @@ def run_case(ref_audiodec, name, model, n_streams, schedule, one_shot_len=None):
         pos = 0
         with torch.no_grad():
             for c in chunks:
-                x = torch.from_numpy(audio[streams, pos:pos + c])[:, None, :]
+                x = torch.from_numpy(audio[streams, :, pos:pos + c])
                 pos += c
                 z_ = tx.encode(x)
                 i_, m_ = tx.quantize(z_, return_margin=True)
@@ -308,6 +310,8 @@ CASES = {
     # HiFiGANResidualBlock(use_additional_convs=False) (residual_block.py:100-105), grouped (v1-shaped) and MRF (v0-shaped)
     "test_v1_noaddl_stream": ("test_v1_noaddl", 2, LONG, None),
     "test_v0_noaddl_stream": ("test_v0_noaddl", 1, LONG, None),
+    # input_channels = output_channels = 2 (AudioDec.py:229-231; no released config, the generator takes the parameters)
+    "test_stereo_sym_stream": ("test_stereo_sym", 2, LONG, None),
 }
 
 

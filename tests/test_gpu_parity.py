@@ -13,7 +13,7 @@ import torch
 from audiodec_amd import configs, synth
 from oracle import audiodec_oracle as O
 import op_cases as C
-from test_oracle_golden import build_oracle, explain_flips, golden_chunks
+from test_oracle_golden import golden_audio, build_oracle, explain_flips, golden_chunks
 
 pytestmark = pytest.mark.gpu
 
@@ -299,11 +299,14 @@ def test_split16_range_overflow_is_repaired_by_the_f32_kernels(gpu, ckpt_root, m
 # whole path against the reference's outputs
 # ------------------------------------------------------------------------------------------------
 def run_hip(ad, audio, chunks):
+    """audio (streams, samples) or (streams, channels, samples)"""
     n = audio.shape[0]
+    if audio.ndim == 2:
+        audio = audio[:, None, :]
     pos, z_l, i_l, q_l, y_l = 0, [], [], [], []
     with torch.no_grad():
         for c in chunks:
-            x = torch.from_numpy(audio[:, pos:pos + c])[:, None, :].to(DEV)
+            x = torch.from_numpy(np.ascontiguousarray(audio[:, :, pos:pos + c])).to(DEV)
             pos += c
             z = ad.tx_encoder.encode(x)
             idx = ad.tx_encoder.quantize(z)
@@ -319,13 +322,13 @@ def run_hip(ad, audio, chunks):
                                              ("vctk_v2_stream", 2), ("vctk_v0_stream", 2), ("vctk_activate_sym_stream", 2),
                                              ("vctk_c16h320_sym_stream", 2), ("libritts_v1_stream", 2), ("vctk_denoise_stream", 2),
                                              ("vctk_univ_stream", 2), ("vctk_univ_sym_stream", 2),
-                                             ("test_v1_noaddl_stream", 2), ("test_v0_noaddl_stream", 2)])
+                                             ("test_v1_noaddl_stream", 2), ("test_v0_noaddl_stream", 2), ("test_stereo_sym_stream", 2)])
 @pytest.mark.parametrize("split16", [False, True], ids=["f32", "split16"])
 def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, max_frames, split16):
     g = _load(golden_dir, name)
     model, seed, n = str(g["model"]), int(g["seed"]), int(g["n_streams"])
     chunks = golden_chunks(g)
-    audio = np.stack([synth.synth_audio(seed, s, sum(chunks)) for s in range(n)])
+    audio = golden_audio(g, sum(chunks))
     from audiodec_amd import native
     native.set_option("chain_min_blocks", 0 if split16 else 160)     # split16: the residual chains run as one launch even for these 1-2 streams
     try:

@@ -210,13 +210,18 @@ def test_extra_aliases_are_not_reference_names():
     from audiodec_amd import configs, arch
     for name in configs.EXTRA_ALIASES:
         sr, enc, dec = configs.checkpoint_paths(name)
-        assert dec.startswith("exp/vocoder/test_")
+        assert "/test_" in dec
         with pytest.raises(NotImplementedError):
             configs.assign_model(name)
-        _, _, _, dec_tag, _ = configs.alias(name)
+        _, enc_tag, _, dec_tag, _ = configs.alias(name)
         _, _, p = configs.experiment(dec_tag)
-        assert p["use_additional_convs"] is False
-        assert not any(".convs2." in s.name for s in arch.hifigan_convs(p))
+        if "noaddl" in name:
+            assert p["use_additional_convs"] is False
+            assert not any(".convs2." in s.name for s in arch.hifigan_convs(p))
+        if "stereo" in name:                                   # input_channels = output_channels = 2 (AudioDec.py:229-231)
+            pe = configs.experiment(enc_tag)[2]
+            assert pe["input_channels"] == pe["output_channels"] == 2
+            assert arch.autoencoder_encoder_convs(pe)[0].cin == 2 and arch.autoencoder_decoder_convs(pe)[-1].cout == 2
 
 
 def test_committed_bench_line_keeps_the_contract():

@@ -54,6 +54,14 @@ def build_oracle_shared_warmup(model, batch, seed):
     return widen_oracle(tx, batch), rx, widen_oracle(dec, batch)
 
 
+def golden_audio(g, total):
+    """(n_streams, in_ch, total): stream s = channels [s * in_ch, (s + 1) * in_ch) of the seeded audio (mono models: in_ch = 1),
+    exactly as tests/golden/make_golden.py fed the reference."""
+    model, seed, n = str(g["model"]), int(g["seed"]), int(g["n_streams"])
+    in_ch = configs.experiment(configs.alias(model)[1])[2].get("input_channels", 1)
+    return np.stack([synth.synth_audio(seed, s, total) for s in range(n * in_ch)]).reshape(n, in_ch, total)
+
+
 def golden_chunks(g):
     hop = int(g["hop"])
     if int(g["one_shot_len"]) > 0:
@@ -78,7 +86,8 @@ def explain_flips(idx, ref_idx, margin, what):
 CASES = ["vctk_sym_stream", "vctk_v1_stream", "libritts_sym_file", "vctk_v0_stream", "vctk_v2_stream",
          "vctk_activate_sym_stream", "vctk_c16h320_sym_stream", "libritts_v1_stream", "vctk_denoise_stream",
          "vctk_univ_stream", "vctk_univ_sym_stream",          # all 11 aliases of utils/audiodec.py:109-179
-         "test_v1_noaddl_stream", "test_v0_noaddl_stream"]    # + use_additional_convs=False (configs.EXTRA_ALIASES)
+         "test_v1_noaddl_stream", "test_v0_noaddl_stream",    # + use_additional_convs=False (configs.EXTRA_ALIASES)
+         "test_stereo_sym_stream"]                            # + input_channels = output_channels = 2
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -87,14 +96,14 @@ def test_oracle_matches_reference_fixture(golden_dir, name):
     g = _load(golden_dir, name)
     model, seed, n = str(g["model"]), int(g["seed"]), int(g["n_streams"])
     chunks = golden_chunks(g)
-    audio = np.stack([synth.synth_audio(seed, s, sum(chunks)) for s in range(n)])
+    audio = golden_audio(g, sum(chunks))
     zs, idxs, ys = [], [], []
     for s in range(n):                                   # B streams = B batch-1 instances
         tx, rx, dec = build_oracle(model, 1, seed)
         pos, z_l, i_l, y_l = 0, [], [], []
         with torch.no_grad():
             for c in chunks:
-                x = torch.from_numpy(audio[s:s + 1, pos:pos + c])[:, None, :]
+                x = torch.from_numpy(audio[s:s + 1, :, pos:pos + c])
                 pos += c
                 z = tx.encode(x)
                 idx = tx.quantize(z)
