@@ -5,6 +5,7 @@
 //               (models/vocoder/HiFiGAN.py:276-279)
 #include "adk_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace adk {
 
@@ -244,6 +245,111 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v2_kernel(const float*
     if (zq && owner && row0 + wave < n_rows) zq[(size_t)(row0 + wave) * D + lane] = qsum;
 }
 
+// max over the lanes of a wave by DPP (no LDS traffic): after the four row steps every lane holds its 16-lane row's maximum, after the
+// two broadcast steps lane 63 holds the wave's.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float m) {
+    const int b = __float_as_int(m);
+    return fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xF, false)));
+}
+__device__ __forceinline__ float row_max16(float m) {
+    m = dpp_max_step<0xB1, 0xF>(m);                        // quad_perm [1,0,3,2]
+    m = dpp_max_step<0x4E, 0xF>(m);                        // quad_perm [2,3,0,1]
+    m = dpp_max_step<0x141, 0xF>(m);                       // row_half_mirror
+    return dpp_max_step<0x140, 0xF>(m);                    // row_mirror
+}
+// (value, lane) of the greatest value of a wave, lowest lane among equals -- what the shuffle tree of argmax_merge returns for i = lane
+__device__ __forceinline__ int wave_argmax_lane(float v, float& vmax) {
+    float m = row_max16(v);
+    m = dpp_max_step<0x142, 0xA>(m);                       // row_bcast:15 into rows 1 and 3
+    m = dpp_max_step<0x143, 0xC>(m);                       // row_bcast:31 into rows 2 and 3
+    vmax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+    const unsigned long long hit = __ballot(v == vmax);
+    return hit ? __builtin_ctzll(hit) : 0;                 // (no lane compares equal only if every value is NaN)
+}
+
+// ---- v3: v2 with a shorter serial chain per stage (dim == 64, size == 1024, one row per workgroup) ----
+// v2 keeps the 64 code registers until the winner has handed its code over through LDS (every thread folds the 16 candidates, one
+// writes 256 bytes, barrier, the owner reads them).  Here only the owner wave folds the candidates and fetches the winning code from
+// memory (one 64-lane gather of L2-hot lines), so the registers are free as soon as barrier A has passed: all waves request the next
+// stage's 256 KB right there, and they land under the owner's residual update and barrier B.  Two barriers per stage instead of
+// three; per element the same operations in the same order as v1 / v2 (the indices and the sum of codes are bit-identical).
+__global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v3_kernel(const float* __restrict__ z, const float* __restrict__ embed,
+                                                                    const float* __restrict__ enorm, long long* __restrict__ idx,
+                                                                    float* __restrict__ zq, int n_rows, int n_q) {
+    constexpr int D = 64, SIZE = 1024;
+    __shared__ __attribute__((aligned(16))) float r2_sh[D];        // 2*r: read as 16 broadcast float4
+    __shared__ float rn_sh;
+    __shared__ float red_v[RVQ_WAVES];
+    __shared__ int red_i[RVQ_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.x;
+    float r_reg = 0.f, qsum = 0.f;
+    float e[D];
+    {
+        const float* Ec = embed + tid;
+#pragma unroll
+        for (int d = 0; d < D; ++d) e[d] = Ec[(size_t)d * SIZE];
+    }
+    float en = enorm[tid];
+    if (wave == 0) {
+        r_reg = z[(size_t)row * D + lane];
+        r2_sh[lane] = 2.f * r_reg;
+        float v = __fmul_rn(r_reg, r_reg);                 // flatten.pow(2).sum(1): the butterfly of v1
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+        if (lane == 0) rn_sh = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < n_q; ++st) {
+        const bool has_next = st + 1 < n_q;
+        const float* En = embed + (size_t)(has_next ? st + 1 : st) * D * SIZE + tid;     // (last stage: re-reads its own codes, unused)
+        float acc = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < D / 4; ++d4) {               // (2*flatten) @ embed, d ascending (vq_module.py:95)
+            const float4 r2 = *reinterpret_cast<const float4*>(&r2_sh[4 * d4]);
+            acc = fmaf(r2.x, e[4 * d4], acc); acc = fmaf(r2.y, e[4 * d4 + 1], acc);
+            acc = fmaf(r2.z, e[4 * d4 + 2], acc); acc = fmaf(r2.w, e[4 * d4 + 3], acc);
+        }
+        float v = -__fadd_rn(__fsub_rn(rn_sh, acc), en);   // dist = (|r|^2 - 2rE) + |E|^2 ; argmax(-dist), lowest index on ties
+        float vmax;
+        const int best_lane = wave_argmax_lane(v, vmax);
+        if (lane == 0) { red_v[wave] = vmax; red_i[wave] = (wave << 6) + best_lane; }
+        __syncthreads();                                   // A: candidates of all waves visible
+        float q = 0.f;
+        if (wave == 0) {
+            // the 16 candidates are in index order: the first wave that holds the maximum wins (greater value, else smaller index)
+            const float cv = red_v[lane & 15];
+            const float cmax = row_max16(cv);
+            const unsigned long long hit = __ballot(cv == cmax);
+            const int bi = red_i[hit ? __builtin_ctzll(hit) : 0];
+            if (lane == 0) idx[(size_t)st * n_rows + row] = (long long)bi + (long long)SIZE * st;
+            q = embed[((size_t)st * D + lane) * SIZE + bi];         // the winning code: one 64-lane gather of L2-hot lines, lane = dimension
+        }
+        // every wave's codes of the next stage: requested here, they land under the owner's update, barrier B and -- the tail of
+        // them -- the first FMAs of the next stage.  In the owner wave they go out BEHIND the gather: loads of a wave return in
+        // order, issued earlier (right after the FMA that frees a register) they hold the gather back for the whole stream --
+        // measured 41 us per launch instead of 36; fetching the winner through the scalar cache instead (64 s_load_dword): 44 us.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) e[d] = En[(size_t)d * SIZE];
+        en = enorm[(size_t)(has_next ? st + 1 : st) * SIZE + tid];
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave == 0) {                                   // straight-through + residual (vq_module.py:101-102,143-144)
+            const float qp = __fadd_rn(r_reg, __fsub_rn(q, r_reg));
+            r_reg = __fsub_rn(r_reg, qp);
+            qsum = __fadd_rn(qsum, qp);
+            r2_sh[lane] = 2.f * r_reg;
+            float s2 = __fmul_rn(r_reg, r_reg);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s2 = __fadd_rn(s2, __shfl_xor(s2, off, 64));
+            if (lane == 0) rn_sh = s2;
+        }
+        __syncthreads();                                   // B: residual of the next stage visible
+    }
+    if (zq && wave == 0) zq[(size_t)row * D + lane] = qsum;
+}
+
 __global__ __launch_bounds__(256) void rvq_lookup_kernel(const long long* __restrict__ idx, const float* __restrict__ codebook,
                                                          float* __restrict__ zq, int n_rows, int n_q, int dim, int n_codes) {
     const int d4 = dim / 4;
@@ -343,13 +449,20 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
     if (n_rows == 0) return ADK_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     DeviceGuard guard(device_of(z));
-    static int variant = -1;                              // ADK_RVQ_V1=1: the first-round kernel (A/B and cross-checks)
+    static int variant = -1;                              // ADK_RVQ_V1=1: the first-round kernel, ADK_RVQ_V=2: the round-2 one (A/B and cross-checks)
     static int rb_env = 0;                                // ADK_RVQ_MAXROWS: largest row count the v2 kernel takes (tuning; default 256)
     if (variant < 0) {
-        const char* e = getenv("ADK_RVQ_V1"); variant = (e && atoi(e) == 1) ? 1 : 2;
+        const char* e = getenv("ADK_RVQ_V1"); variant = (e && atoi(e) == 1) ? 1 : 3;
+        e = getenv("ADK_RVQ_V"); if (e && variant != 1 && atoi(e) >= 1 && atoi(e) <= 3) variant = atoi(e);
         e = getenv("ADK_RVQ_MAXROWS"); rb_env = e ? atoi(e) : 0;
     }
-    if (variant == 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 256)) {
+    if (variant >= 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 256)) {
+        if (variant == 3) {
+            hipLaunchKernelGGL(rvq_encode_v3_kernel, dim3(n_rows), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
+                               reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
+            ADK_HIP_CHECK(hipGetLastError());
+            return ADK_OK;
+        }
         // the latency kernel: one workgroup per row -- one dispatch round up to 256 rows (measured 37 us for 1..32 rows, 43 us
         // for 256, against 77-78 us of the first-round kernel; at 512 rows = two rounds it only ties, 80 vs 79 us, because each
         // workgroup streams the 2 MB of codes from L2, so the 4-rows-per-workgroup kernel below keeps the large row counts)

@@ -610,6 +610,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--preroll", type=int, default=64,
+                    help="untimed steps BEFORE the warm-up steps: the device sat idle while the models were built, and the first "
+                         "tens of milliseconds after idle run at lower clocks (profiles/r3_short_runs.md); reported as "
+                         "preroll_steps.  0 = none")
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
     ap.add_argument("--frames-per-step", type=int, default=1, help="hops per stream per step (headline: 1)")
     ap.add_argument("--serial", action="store_true", help="one HIP stream (no transmitter/receiver overlap)")
@@ -715,6 +719,14 @@ def main():
         pipe = None if args.serial else TxRxPipeline(ad, dev)
     run = (lambda x: step(ad, x)) if pipe is None else pipe.step
     with torch.no_grad():
+        if args.preroll > 0:                       # wake the device up; its own region, drained before the warm-up starts
+            if pipe:
+                pipe.enter()
+            for i in range(args.preroll):
+                run(xs[i % n_buf])
+            if pipe:
+                pipe.exit()
+            sync_all()
         if pipe:
             pipe.enter()
         for i in range(args.warmup):
@@ -741,7 +753,7 @@ def main():
     out = {
         "metric": "48 kHz hop-300 frames/s/GPU + per-frame encode+decode latency (ms)",
         "value": round(frames / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "preroll_steps": args.preroll, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "f32" else "f32 (conv operands split into f16 hi + lo/2048 pairs, 3 f16 MFMAs per product sum, f32 accumulate)",
         "data": "synthetic",

@@ -391,6 +391,33 @@ def test_rvq_indices_bit_exact_on_reference_latents(gpu, golden_dir):
         explain_flips(idx, g["idx"], g["margin"], name + " (reference z)")
 
 
+@pytest.mark.parametrize("rows", [1, 5, 256, 300])
+def test_rvq_exact_ties_pick_the_lowest_index(gpu, rows):
+    """`(-dist).max(1)` returns the lowest index among equal maxima (vq_module.py:97): duplicate codes inside one wave of the
+    search (64 consecutive codes), across waves, and in every stage, with rows sitting exactly on them -- on the one-row-per-
+    workgroup kernel (<= 256 rows: DPP arg-max, owner-only fold) and on the 4-rows kernel (300 rows), against the oracle."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(4242 + rows)
+    embeds = [torch.randn(64, 1024, generator=g) * (0.8 ** i) for i in range(8)]
+    for st in range(8):
+        a = 64 * st + 3
+        embeds[st][:, a + 17] = embeds[st][:, a]           # same wave
+        embeds[st][:, 1000 - st] = embeds[st][:, a]        # another wave
+        embeds[st][:, 5 + st] = embeds[st][:, 900 + st]    # the duplicate with the LOWER index comes later in memory order of the pair
+    x = torch.randn(1, rows, 64, generator=g)
+    x[0, 0] = embeds[0][:, 3]                              # row 0 sits exactly on the three-way tie of stage 0
+    if rows > 3:
+        x[0, 3] = embeds[0][:, 900]                        # ... and row 3 on the (5, 900) pair
+    want_q, want_idx = O.rvq_forward_index(x, embeds, flatten_idx=True)
+    rvq = layers.ResidualVQ(embeds, device=gpu)
+    q, idx = rvq.forward_index(x, flatten_idx=True)
+    idx = idx.cpu().numpy()
+    assert np.array_equal(idx, want_idx.numpy()), np.argwhere(idx != want_idx.numpy())[:5]
+    assert int(idx[0, 0]) == 3 and (rows <= 3 or int(idx[0, 3]) == 5)
+    assert np.abs(q.cpu().numpy() - want_q.numpy()).max() < 1e-5
+    assert native.device_flags() == 0
+
+
 def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
     """Streaming invariants on the HIP path.  Chunking must not change the codes
     and may change the waveform only by fp32 round-off (the stream-K schedule splits the K sum of a

@@ -2,7 +2,7 @@
 // 1-2 minutes on its first `import torch`; this starts in a second).  Tuning aid, not part of the product.
 //
 //   kbench conv <shape> <impl> [B=256] [iters=200] [ref_impl=-1]   time one fused conv; ref_impl >= 0: max|diff| against that kernel
-//   kbench rvq [rows=256] [iters=200]                               time adk_rvq_encode; prints an index checksum (compare ADK_RVQ_V1=1)
+//   kbench rvq [rows=256] [iters=200]                               time adk_rvq_encode; prints an index checksum (compare ADK_RVQ_V1=1 / ADK_RVQ_V=2)
 //
 // shapes: see kShapes below (the layers of the vctk_v1 pipeline at one frame per stream).
 // Build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include tools/kbench.cpp -L audiodec_amd -laudiodec_hip -Wl,-rpath,'$ORIGIN/../../audiodec_amd' -o tools/bin/kbench
@@ -213,7 +213,7 @@ static int cmd_rvq(int argc, char** argv) {
     unsigned long long ck = 1469598103934665603ull; for (int64_t v : hi) { ck ^= (unsigned long long)v; ck *= 1099511628211ull; }
     unsigned long long cq = 1469598103934665603ull; for (float v : hq) { unsigned u; memcpy(&u, &v, 4); cq ^= u; cq *= 1099511628211ull; }
     printf("rvq rows=%d  %8.2f us per launch   idx checksum %016llx  zq checksum %016llx  (variant %s)\n", rows, 1e3 * ms / iters, ck, cq,
-           getenv("ADK_RVQ_V1") ? "v1" : "default");
+           getenv("ADK_RVQ_V1") ? "v1" : getenv("ADK_RVQ_V") ? getenv("ADK_RVQ_V") : "default");
     return 0;
 }
 
