@@ -238,6 +238,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(gpu):
     assert out["n_gpus"] == 2 and out["config"]["streams_total"] == 512 and out["config"]["streams_per_gpu"] == 256
     assert out["scaling"] == "weak" and out["steps"] == 6 and out["device_error_flags"] == 0
     assert out["value"] > 0 and abs(out["value"] - 512 * 6 / (out["ms_per_step"] * 6e-3)) < 0.01 * out["value"]
+    assert out["roofline"]["kernel"].startswith("conv_") and 0 < out["roofline"]["frac"] < 1      # rank 0 prices its kernels at every N
+    assert "cpu_baseline" not in out and "self_check" not in out                                   # single-GPU legs stay at N = 1
     # without the rehearsal hook a box with fewer devices than ranks is an error, not a silent 1-rank run
     env.pop("ADK_BENCH_ONE_GPU")
     if torch.cuda.device_count() < 8:
