@@ -67,12 +67,18 @@ class TxRxPipeline:
 
     def __init__(self, ad, dev):
         self.ad, self.dev = ad, dev
-        self.s_tx, self.s_rx = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # HIP stream priorities of the transmitter, the receiver and the further vocoder stages (ADK_BENCH_PRIO, 0 / -1).  The
+        # transmitter -- head of the pipeline, and the program with the most short latency-bound launches (one column per stream
+        # behind the last strided conv, the 8 dependent RVQ stages) -- runs at high priority: 100 steps, three runs each on one box,
+        # 249.0-249.4 k frames/s with all three equal, 250.4-253.1 k with the transmitter high, 251.6-252.3 k with transmitter and
+        # receiver high; no measurable difference over 20 steps
+        prio = [int(v) for v in os.environ.get("ADK_BENCH_PRIO", "-1,0,0,0").split(",")] + [0, 0, 0, 0]
+        self.s_tx, self.s_rx = torch.cuda.Stream(dev, priority=prio[0]), torch.cuda.Stream(dev, priority=prio[1])
         # a vocoder lowered in two stages (set_stages) gets a third stream: its second half of batch i runs under the
         # first half of batch i+1 and the encoder of batch i+2
         self.n_dec = getattr(ad.decoder, "stages", 1)
         self.two = self.n_dec >= 2
-        self.s_more = [torch.cuda.Stream(dev) for _ in range(self.n_dec - 1)]
+        self.s_more = [torch.cuda.Stream(dev, priority=prio[2 + i]) for i in range(self.n_dec - 1)]
         # ADK_BENCH_WORKGROUPS (tuning): cap on the persistent workgroups of a stream-K launch.  Round 1 ran the three
         # concurrent programs with 256 (half the chip's slots each: 210 k frames/s vs 189 k at 512); with tile-aligned ranges
         # (round 2) the library default -- up to 512, e.g. exact halves of the 240 tiles of a stage-0 grouped conv -- is as fast
