@@ -855,7 +855,7 @@ def main():
                 n2 = max(20, args.steps // 2)
                 if pipe2:
                     pipe2.enter()
-                for i in range(5):
+                for i in range(5 + args.preroll):          # (built on the host while the device idled: same pre-roll as the headline)
                     run2(xs[i % n_buf])
                 if pipe2:
                     pipe2.exit()
