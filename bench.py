@@ -67,12 +67,11 @@ class TxRxPipeline:
 
     def __init__(self, ad, dev):
         self.ad, self.dev = ad, dev
-        # HIP stream priorities of the transmitter, the receiver and the further vocoder stages (ADK_BENCH_PRIO, 0 / -1).  The
-        # transmitter -- head of the pipeline, and the program with the most short latency-bound launches (one column per stream
-        # behind the last strided conv, the 8 dependent RVQ stages) -- runs at high priority: 100 steps, three runs each on one box,
-        # 249.0-249.4 k frames/s with all three equal, 250.4-253.1 k with the transmitter high, 251.6-252.3 k with transmitter and
-        # receiver high; no measurable difference over 20 steps
-        prio = [int(v) for v in os.environ.get("ADK_BENCH_PRIO", "-1,0,0,0").split(",")] + [0, 0, 0, 0]
+        # ADK_BENCH_PRIO (tuning): HIP stream priorities of the transmitter, the receiver and the further vocoder stages (0 / -1).
+        # Measured, 100 steps, three runs each on one box: all equal 249.0-249.4 k frames/s, transmitter high 250.4-253.1 k, no
+        # difference over 20 steps -- but a SECOND pipeline object with a high-priority stream in the same process (the
+        # other-precision leg) then ran 12 % slower (111.7 k vs 126.5 k), so the default stays equal priorities
+        prio = [int(v) for v in os.environ.get("ADK_BENCH_PRIO", "0,0,0,0").split(",")] + [0, 0, 0, 0]
         self.s_tx, self.s_rx = torch.cuda.Stream(dev, priority=prio[0]), torch.cuda.Stream(dev, priority=prio[1])
         # a vocoder lowered in two stages (set_stages) gets a third stream: its second half of batch i runs under the
         # first half of batch i+1 and the encoder of batch i+2
