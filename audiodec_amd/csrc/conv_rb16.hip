@@ -32,6 +32,9 @@
 #include <type_traits>
 #include <cstdlib>
 
+#ifndef ADK_RB16_ASYNC_TOUCH
+#define ADK_RB16_ASYNC_TOUCH 1     // 0: the L2 warm-up touches as volatile loads (each one waited for), as measured in profiles/r3_rb16_timeline.md sections 1-3
+#endif
 #ifndef ADK_RB16_DBG
 #define ADK_RB16_DBG 0      // tuning builds only: 1 = per-workgroup wall-clock stamps (s_memrealtime, 100 MHz) at every phase boundary of wave 0;
                             // knock-outs (results are garbage): 2 = no weight loads inside the MFMA loops, 4 = no MFMAs, 8 = one B-fragment read per loop,
@@ -65,6 +68,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRbMaxConvs = 8;
 constexpr int kRbMaxHist = 56;           // rows of causal history a conv of the chain may need ((K-1) * dilation: 54 for K7 d9, 50 for K11 d5)
+constexpr int kRbTouchSink = 256;      // bytes at the end of the dynamic LDS that the L2 warm-up touches (LDS-DMA loads nobody reads) land in
 constexpr float kRbLoScale = 2048.f, kRbLoInv = 1.f / 2048.f;
 
 struct RbNode {                          // a tensor of the chain: where its rows live in HBM (a state ring)
@@ -220,11 +224,30 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     // a conv's weight block are TOUCHED one conv ahead (one dword per 128-byte line, result unused: the hardware has no
     // prefetch instruction), by the waves that will stream it; the fragment loads then find them in L2.  The same for the
     // history rows the later convs fetch from their state rings. ----
+    // A touch is an LDS-DMA load issued through inline asm: the compiler does not know it is a load, so it inserts no s_waitcnt for
+    // it (a volatile load was waited for in EVERY iteration of these loops, one round trip each -- ISA), and its data goes to a 256-byte
+    // sink in LDS that nothing reads, not to a register the allocator might hand to somebody else while the load is in flight.
+    // Nothing ever waits for a touch by name; the compiler's own s_waitcnt vmcnt(n) assume fewer loads in flight than there are
+    // (loads return in order: they wait for more, never for less), and the last touches of a launch go out before the last conv's
+    // MFMA loop, whose weight waits retire them long before the workgroup's LDS is released.
+    typedef unsigned char __attribute__((address_space(3)))* lds_u8_t;
+    const unsigned touch_m0 = (unsigned)(size_t)(lds_u8_t)xs + (unsigned)r.spw * (unsigned)r.rps * (unsigned)RS +
+                              (BIAS_LDS ? (unsigned)r.n_convs * C * 4u : 0u);          // the last kRbTouchSink bytes of the dynamic LDS
+#if ADK_RB16_ASYNC_TOUCH
+#define RB_TOUCH(ptr) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(ptr), "s"(touch_m0) : "m0", "memory")
+#else
+#define RB_TOUCH(ptr) (void)*reinterpret_cast<const volatile unsigned*>(ptr)
+#endif
     auto warm_weights = [&](const RbConv& cv) __attribute__((always_inline)) {
+        // scalar loop counter, scalar block pointer, lane id recomputed: inside the unit loop a register that is reloaded from scratch in
+        // front of this loop would put an s_waitcnt vmcnt(0) INTO it (seen in the ISA), i.e. one round trip per touch again
         const unsigned char* wbp = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)((g * MT + mt) * cv.ksteps) * 2048u;
         const int nlines = cv.ksteps * 16;
-        for (int line = lane + 64 * wi; line < nlines; line += 64 * WM)
-            (void)*reinterpret_cast<const volatile unsigned*>(wbp + (size_t)line * 128u);
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        for (int base_line = 64 * wi; base_line < nlines; base_line += 64 * WM) {
+            const int line = min(base_line + ln, nlines - 1);       // (past the end: the last line again)
+            RB_TOUCH(wbp + (size_t)line * 128u);
+        }
     };
     if (r.warm) warm_weights(r.conv[0]);
     for (int k = 1; k < (r.warm ? r.n_convs : 0); ++k) { // history rows [-hist_k, 0) of node k, all streams of this workgroup: 16 bytes of every 128
@@ -237,7 +260,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
             const int rr = rem_ / LPR, li = rem_ - rr * LPR;
             int row = nd.cursor - hk + rr;
             if (row < 0) row += nd.rows;
-            (void)*reinterpret_cast<const volatile unsigned*>(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 32 * li);
+            RB_TOUCH(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 32 * li);
         }
     }
 
@@ -509,7 +532,7 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     if (pl.hm > kRbMaxHist) return false;
     pl.rps = pl.hm + T;
     const bool bias_lds = pl.C < 128 && !(pl.C == 64 && (pl.spw > 1 || pl.ntw > 2));        // (as BIAS_LDS of the instantiation rb_by_taps picks)
-    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0);
+    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0) + kRbTouchSink;
     if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 2 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
     pl.blocks = (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups;
     return pl.blocks <= 0x7fffffffLL;
