@@ -32,6 +32,9 @@
 #include <type_traits>
 #include <cstdlib>
 
+#ifndef ADK_RB16_PIN_LOADS
+#define ADK_RB16_PIN_LOADS 1
+#endif
 #ifndef ADK_RB16_ASYNC_TOUCH
 #define ADK_RB16_ASYNC_TOUCH 1     // 0: the L2 warm-up touches as volatile loads (each one waited for), as measured in profiles/r3_rb16_timeline.md sections 1-3
 #endif
@@ -129,6 +132,11 @@ __device__ __forceinline__ void rb_mfma(const unsigned char* const (&x)[NTW], in
         if (s + PF < STEPS && !(ADK_RB16_DBG & 2)) {
             ah[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wbase + (unsigned)(s + PF) * 2048u, 0);
             al[(s + PF) % (PF + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wbase + (unsigned)(s + PF) * 2048u, 0);
+#if ADK_RB16_PIN_LOADS
+            // keep the loads HERE: left alone the scheduler sinks each of them to two or three MFMAs in front of its first use (shorter
+            // live ranges), i.e. the prefetch distance collapses from PF steps to ~100 cycles and every step waits out an L2 round trip
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         const int tap = s / CH, ch = s - tap * CH;
         const int off = (ADK_RB16_DBG & 8) ? 0 : tap * dil_rs + 32 * ch;
@@ -234,7 +242,8 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     const unsigned touch_m0 = (unsigned)(size_t)(lds_u8_t)xs + (unsigned)r.spw * (unsigned)r.rps * (unsigned)RS +
                               (BIAS_LDS ? (unsigned)r.n_convs * C * 4u : 0u);          // the last kRbTouchSink bytes of the dynamic LDS
 #if ADK_RB16_ASYNC_TOUCH
-#define RB_TOUCH(ptr) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(ptr), "s"(touch_m0) : "m0", "memory")
+#define RB_TOUCH(ptr) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" \
+                                                        : "=&s"(m0_keep_) : "v"(ptr), "s"(touch_m0) : "memory"); } while (0)      /* M0 is the compiler's: put back */
 #else
 #define RB_TOUCH(ptr) (void)*reinterpret_cast<const volatile unsigned*>(ptr)
 #endif
