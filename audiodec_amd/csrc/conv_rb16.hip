@@ -32,6 +32,15 @@
 #include <type_traits>
 #include <cstdlib>
 
+#ifndef ADK_RB16_PF32
+#define ADK_RB16_PF32 2            // weight prefetch distance in 16-k steps of the variants in use (tuning builds: -DADK_RB16_PF32=... etc.)
+#endif
+#ifndef ADK_RB16_PF64
+#define ADK_RB16_PF64 2
+#endif
+#ifndef ADK_RB16_PF128
+#define ADK_RB16_PF128 3           // (with the loads pinned: 2 / 3 / 4 / 5 / 6 -> 259.3 / 262.0 / 259.7 / 257.7 / ~250 k frames/s on one box; 6 was the unpinned choice)
+#endif
 #ifndef ADK_RB16_PIN_LOADS
 #define ADK_RB16_PIN_LOADS 1
 #endif
@@ -657,16 +666,16 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     // carried two waves of every co-resident workgroup and a second 5-wave workgroup did not even fit at 168 registers --
     // profiles/r3_rb16_timeline.md.  Now 4 waves x (3, 3, 2, 2) tiles, the odd tiles rotating with the workgroup.)
     if (pl.C == 32) {
-        if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, 2, true, 0>(r, pl, act, s);
-        if (pl.ntw == 3) return rb_by_taps<32, 3, 1, 2, 2, true, 0>(r, pl, act, s);
+        if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, ADK_RB16_PF32, true, 0>(r, pl, act, s);
+        if (pl.ntw == 3) return rb_by_taps<32, 3, 1, 2, ADK_RB16_PF32, true, 0>(r, pl, act, s);
         return rb_by_taps<32, 4, 1, 2, 2, false, 0>(r, pl, act, s);
     }
     if (pl.C == 64) {
-        if (pl.ntw == 2 && pl.spw == 1) return rb_by_taps<64, 2, 1, 3, 2, true, 0>(r, pl, act, s);
+        if (pl.ntw == 2 && pl.spw == 1) return rb_by_taps<64, 2, 1, 3, ADK_RB16_PF64, true, 0>(r, pl, act, s);
         if (pl.ntw <= 3) return rb_by_taps<64, 3, 2, 2, 2, true, 0>(r, pl, act, s);
         return rb_by_taps<64, 4, 2, 2, 2, false, 0>(r, pl, act, s);
     }
-    return rb_by_taps<128, 2, 2, 2, 6, true, 4>(r, pl, act, s);
+    return rb_by_taps<128, 2, 2, 2, ADK_RB16_PF128, true, 4>(r, pl, act, s);
 }
 
 const char* conv_rb16_name(const ConvArgs* c, int n) {
