@@ -660,8 +660,8 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
 #endif
     const int act = a0.act_in;
     // Register budgets.  Two n-tiles per wave: 168 registers (three 4-wave workgroups per CU), the residual fetched under the second
-    // conv's MFMAs; three: 256 (two workgroups), residual early; four: 256, residual after the loop.  128 channels: 256, which also
-    // buys a prefetch distance of 6 steps, and the waves re-align every 4 steps (LS).
+    // conv's MFMAs; three: 256 (two workgroups), residual early; four: 256, residual after the loop.  128 channels: 256, prefetch
+    // distance 3 steps (ADK_RB16_PF128), and the waves re-align every 4 steps (LS).
     // (32 channels used to run as 5 waves x 2 tiles: the hardware starts every workgroup's waves on the same SIMD, so one SIMD
     // carried two waves of every co-resident workgroup and a second 5-wave workgroup did not even fit at 168 registers --
     // profiles/r3_rb16_timeline.md.  Now 4 waves x (3, 3, 2, 2) tiles, the odd tiles rotating with the workgroup.)
