@@ -667,6 +667,10 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     // profiles/r3_rb16_timeline.md.  Now 4 waves x (3, 3, 2, 2) tiles, the odd tiles rotating with the workgroup.)
     if (pl.C == 32) {
         if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, ADK_RB16_PF32, true, 0>(r, pl, act, s);
+        // (three tiles, K11 blocks of the vocoder: with the residual fetched AFTER the second conv's loop the kernel has 1 spilled register
+        // instead of 45 -- stage-3 chain 151.6 -> 142.5 us, pipeline +1.2 % on one box; the K7 + 1x1 units of the encoder have no spills
+        // either way and lose 2 us with the late fetch)
+        if (pl.ntw == 3 && pl.ta == 11) return rb_by_taps<32, 3, 1, 2, ADK_RB16_PF32, false, 0>(r, pl, act, s);
         if (pl.ntw == 3) return rb_by_taps<32, 3, 1, 2, ADK_RB16_PF32, true, 0>(r, pl, act, s);
         return rb_by_taps<32, 4, 1, 2, 2, false, 0>(r, pl, act, s);
     }
