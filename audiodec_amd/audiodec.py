@@ -26,7 +26,7 @@ class AudioDec(AudioCodec):
         receptive_length: int = 8192,  # actual number is 7209 for symAD_vctk_48000_hop300
         num_streams: int = 1,
         max_frames: int = 16,
-        guard: bool = True,
+        guard: bool = None,
     ):
         # The signature keeps the reference's 'cpu' defaults (utils/audiodec.py:20-30) so that callers port unchanged, but
         # this package has no CPU compute path: 'cpu' becomes the first HIP device (with a warning), and without a HIP
@@ -38,7 +38,8 @@ class AudioDec(AudioCodec):
         self.num_streams = num_streams
         self.max_frames = max_frames
         # guard=True: every program step is checked on the device and a split-f16 range overflow is repaired in place by the
-        # exact-f32 kernels (stream_generator.set_guard); False for callers that keep several steps in flight (bench.py)
+        # exact-f32 kernels (stream_generator.set_guard); False for callers that keep several steps in flight (bench.py);
+        # None (default): the generators' own default -- on, unless the environment says ADK_GUARD=0
         self.guard = guard
 
     def _load_encoder(self, checkpoint):

@@ -90,9 +90,15 @@ int conv_sk16_pick(const ConvArgs& a);
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 int* flags_word();                                   // address of the sticky debug/error flags ON THE CURRENT DEVICE
 inline int* conv_err_word(const ConvArgs& a) { return a.err ? a.err : flags_word(); }
-// OR of the flag words of every live program on `device` (each fetched and cleared atomically); the device must be current and idle
-int fetch_clear_program_flags(int device, int* acc);
 constexpr int kMaxDevices = 64;
+// Per-device pool of sticky flag words (rvq.hip): every program owns one slot for its lifetime; each slot has a pinned, device-mapped
+// host mirror, so reading a word is one 1-thread kernel (atomic exchange -> host mirror) + a stream synchronisation, no copy.
+// `device` must be current.  flag_pool_fetch_all ORs and clears EVERY slot of the device (live programs or not: free slots are 0)
+// plus the device word, on the null stream, in one sweep -- it needs no list of programs and takes no lock programs wait for.
+int flag_pool_acquire(int device, int** word);
+void flag_pool_release(int device, int* word);
+int flag_pool_fetch(int device, int* word, hipStream_t s, int* v);
+int flag_pool_fetch_all(int device, int* acc);
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
 // Makes `device` current for the lifetime of the object (programs are bound to the device they were created on,
 // whatever device the calling thread has current); restores the previous one.

@@ -268,8 +268,12 @@ int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s) {
     u.err = conv_err_word(a1);
     const int mt2 = a2.cout_g / 32;
     const size_t lds = (size_t)2 * u.ks1p * 2048 + (size_t)mt2 * OU_KS2 * 2048 + (size_t)(1 + OU_TMAX) * OU_RSC + (size_t)(32 * mt2 + OU_CM) * sizeof(float);
-    auto go = [&](auto kern) -> int {
-        static bool attr_set_dev[kMaxDevices] = {};
+    // a function attribute belongs to ONE instantiation (and one device): the flags are keyed by the (ACT, MT2) pair -- every
+    // instantiation decays to the same pointer type, so a flag inside a generic lambda over that pointer would be shared by all of them
+    auto go = [&](auto act, auto mt) -> int {
+        constexpr int ACT = decltype(act)::value, MT2 = decltype(mt)::value;
+        auto kern = conv_ou16_kernel<ACT, 12, MT2>;
+        static bool attr_set_dev[kMaxDevices] = {};         // one array per (ACT, MT2): the lambda's operator() is instantiated per tag type pair
         bool& attr_set = attr_set_dev[current_device()];
         if (!attr_set) {
             ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -280,10 +284,9 @@ int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s) {
         return ADK_OK;
     };
     auto by_mt = [&](auto act) -> int {
-        constexpr int ACT = decltype(act)::value;
-        if (mt2 == 1) return go(conv_ou16_kernel<ACT, 12, 1>);
-        if (mt2 == 2) return go(conv_ou16_kernel<ACT, 12, 2>);
-        return go(conv_ou16_kernel<ACT, 12, 3>);
+        if (mt2 == 1) return go(act, std::integral_constant<int, 1>());
+        if (mt2 == 2) return go(act, std::integral_constant<int, 2>());
+        return go(act, std::integral_constant<int, 3>());
     };
     if (a2.act_in == ADK_ACT_ELU) return by_mt(std::integral_constant<int, ADK_ACT_ELU>());
     if (a2.act_in == ADK_ACT_LEAKY) return by_mt(std::integral_constant<int, ADK_ACT_LEAKY>());

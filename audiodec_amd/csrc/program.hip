@@ -256,10 +256,10 @@ struct adk_program {
     const float* weights = nullptr; int64_t weights_floats = 0;
     float* arena = nullptr; int64_t arena_floats = 0;
     Workspace ws;
-    int* flags = nullptr;           // this program's sticky device flag word (bits as adk_debug_flags): what its launches report to
-    int* flags_out = nullptr;       // staging word for adk_program_flags
+    int* flags = nullptr;           // this program's sticky device flag word (bits as adk_debug_flags): what its launches report to; a slot of the device's pool
     bool profiling = false;
     bool fresh = true;              // no step since create / reset (ADK_OP_HIST_REPLICATE runs only then)
+    bool fresh_before = true;       // ... as it was before the last step (adk_program_rewind puts it back)
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
     std::vector<float> last_ms;
     // HIP-graph replay of the steady state (adk_program_set_graph): one captured graph per cursor phase
@@ -271,32 +271,7 @@ struct adk_program {
     long long replays = 0, captures = 0;
 };
 
-static std::mutex g_prog_mu;
-static std::vector<adk_program*> g_programs;          // live programs (for adk_debug_flags)
-
-__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); }
-
-static int program_fetch_clear(adk_program* p, hipStream_t s, int* v) {
-    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, s, p->flags, p->flags_out);
-    ADK_HIP_CHECK(hipGetLastError());
-    ADK_HIP_CHECK(hipMemcpyAsync(v, p->flags_out, sizeof(int), hipMemcpyDeviceToHost, s));
-    ADK_HIP_CHECK(hipStreamSynchronize(s));
-    return ADK_OK;
-}
-
-namespace adk {
-int fetch_clear_program_flags(int device, int* acc) {
-    std::lock_guard<std::mutex> lk(g_prog_mu);
-    for (adk_program* p : g_programs) {
-        if (p->device != device) continue;
-        int v = 0;
-        const int rc = program_fetch_clear(p, nullptr, &v);
-        if (rc != ADK_OK) return rc;
-        *acc |= v;
-    }
-    return ADK_OK;
-}
-}  // namespace adk
+static int program_fetch_clear(adk_program* p, hipStream_t s, int* v) { return flag_pool_fetch(p->device, p->flags, s, v); }
 
 extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const adk_ring_desc* rings, int32_t n_rings,
                                   int32_t batch, int32_t max_frames, const float* weights, int64_t weights_floats,
@@ -376,16 +351,12 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
     {
         int rc = ensure_workspace(p->ws);
         if (rc != ADK_OK) { delete p; return rc; }
-        if (hipMalloc(reinterpret_cast<void**>(&p->flags), 2 * sizeof(int)) != hipSuccess || hipMemset(p->flags, 0, 2 * sizeof(int)) != hipSuccess) {
+        rc = flag_pool_acquire(p->device, &p->flags);
+        if (rc != ADK_OK) {
             if (p->ws.ptr) (void)hipFree(p->ws.ptr);
             delete p;
-            return fail(ADK_ERR_HIP, "program_create: cannot allocate the flag word");
+            return rc;
         }
-        p->flags_out = p->flags + 1;
-    }
-    {
-        std::lock_guard<std::mutex> lk(g_prog_mu);
-        g_programs.push_back(p);
     }
     *out = p;
     return ADK_OK;
@@ -393,14 +364,10 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
 
 extern "C" void adk_program_destroy(adk_program* p) {
     if (!p) return;
-    {
-        std::lock_guard<std::mutex> lk(g_prog_mu);
-        g_programs.erase(std::remove(g_programs.begin(), g_programs.end(), p), g_programs.end());
-    }
     DeviceGuard guard(p->device);
     for (hipGraphExec_t g : p->gexec) if (g) (void)hipGraphExecDestroy(g);
     if (p->ws.ptr) (void)hipFree(p->ws.ptr);
-    if (p->flags) (void)hipFree(p->flags);
+    flag_pool_release(p->device, p->flags);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
 }
@@ -610,6 +577,7 @@ extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext
     const int phase = (p->graph && !p->profiling && !p->fresh && frames == p->max_frames) ? graph_phase(p) : -1;
     const bool replay = phase >= 0 && p->seen[phase] && s != nullptr;      // the legacy default stream cannot be captured: eager there
     if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[0], s));
+    p->fresh_before = p->fresh;
     for (int i = 0; i < n_ops; ++i) {
         if (replay && i == p->g_lo) {
             if (!p->gexec[phase]) {
@@ -720,6 +688,15 @@ extern "C" int adk_program_rewind(adk_program* p, int32_t frames) {
             const long long back = ((long long)frames * p->rings[i].rate) % p->rows[i];
             p->cursor[i] = (int32_t)(((long long)p->cursor[i] - back + p->rows[i]) % p->rows[i]);
         }
+    p->fresh = p->fresh_before;               // the repeated step is the first one after a reset iff the rewound one was
+    return ADK_OK;
+}
+
+extern "C" int adk_program_get_fresh(const adk_program* p) { return p ? (p->fresh ? 1 : 0) : fail(ADK_ERR_ARG, "program_get_fresh: null program"); }
+
+extern "C" int adk_program_set_fresh(adk_program* p, int32_t fresh) {
+    if (!p) return fail(ADK_ERR_ARG, "program_set_fresh: null program");
+    p->fresh = p->fresh_before = fresh != 0;
     return ADK_OK;
 }
 

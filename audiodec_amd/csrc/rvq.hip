@@ -5,7 +5,9 @@
 //               (models/vocoder/HiFiGAN.py:276-279)
 #include "adk_common.h"
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <vector>
 
 namespace adk {
 
@@ -513,29 +515,110 @@ extern "C" int adk_ring_write(const float* src, adk_ring_view ring, const float*
     return ADK_OK;
 }
 
+// ---- flag words ----------------------------------------------------------------------------------------------------
+namespace adk {
 // read AND clear in one atomic operation on the device: a bit set by a kernel of another HIP stream or host thread between a
 // separate read and a separate clear would be lost
-__global__ void flags_fetch_clear_kernel(int* out) { *out = atomicExch(&g_adk_flags, 0); }
+constexpr int kFlagSlots = 1024;          // programs alive at the same time on one device (slot 0: the sweep's result)
+struct FlagPool {
+    int* dev = nullptr;                   // kFlagSlots words in device memory: what the kernels atomicOr into
+    volatile int* host = nullptr;         // kFlagSlots pinned host words, mapped into the device: where a fetch lands
+    int* host_dev = nullptr;              // ... their device-side address
+    std::vector<int> free_slots;
+    int next = 1;
+};
+static FlagPool g_pool[kMaxDevices];
+static std::mutex g_pool_mu;              // slot bookkeeping only: never held across a device synchronisation
+
+static int pool_ready(FlagPool& fp) {     // (g_pool_mu held, the pool's device current)
+    if (fp.dev) return ADK_OK;
+    int* d = nullptr; int* h = nullptr; int* hd = nullptr;
+    ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), kFlagSlots * sizeof(int)));
+    ADK_HIP_CHECK(hipMemset(d, 0, kFlagSlots * sizeof(int)));
+    ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), kFlagSlots * sizeof(int), hipHostMallocMapped));
+    memset(h, 0, kFlagSlots * sizeof(int));
+    ADK_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0));
+    fp.dev = d; fp.host = h; fp.host_dev = hd;
+    return ADK_OK;
+}
+
+int flag_pool_acquire(int device, int** word) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    FlagPool& fp = g_pool[device];
+    const int rc = pool_ready(fp);
+    if (rc != ADK_OK) return rc;
+    int slot;
+    if (!fp.free_slots.empty()) { slot = fp.free_slots.back(); fp.free_slots.pop_back(); }
+    else if (fp.next < kFlagSlots) slot = fp.next++;
+    else return fail(ADK_ERR_STATE, "more than 1023 live programs on one device");
+    *word = fp.dev + slot;
+    return ADK_OK;
+}
+
+void flag_pool_release(int device, int* word) {
+    if (!word) return;
+    (void)hipMemset(word, 0, sizeof(int));           // (a released slot reads 0 in the sweep)
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    FlagPool& fp = g_pool[device];
+    if (fp.dev && word > fp.dev && word < fp.dev + kFlagSlots) fp.free_slots.push_back((int)(word - fp.dev));
+}
+
+__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); }
+
+int flag_pool_fetch(int device, int* word, hipStream_t s, int* v) {
+    FlagPool& fp = g_pool[device];
+    if (!fp.dev || word <= fp.dev || word >= fp.dev + kFlagSlots) return fail(ADK_ERR_ARG, "flag word outside the device's pool");
+    const int slot = (int)(word - fp.dev);
+    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, s, word, fp.host_dev + slot);
+    ADK_HIP_CHECK(hipGetLastError());
+    ADK_HIP_CHECK(hipStreamSynchronize(s));
+    *v = fp.host[slot];
+    return ADK_OK;
+}
+
+__global__ void flags_sweep_kernel(int* pool, int n, int* out) {
+    __shared__ int acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    int v = 0;
+    if (pool)
+        for (int i = 1 + threadIdx.x; i < n; i += blockDim.x)
+            if (pool[i]) v |= atomicExch(&pool[i], 0);
+    if (v) atomicOr(&acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = acc | atomicExch(&g_adk_flags, 0);
+}
+
+int flag_pool_fetch_all(int device, int* acc) {
+    FlagPool& fp = g_pool[device];
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        const int rc = pool_ready(fp);
+        if (rc != ADK_OK) return rc;
+    }
+    ADK_HIP_CHECK(hipDeviceSynchronize());             // everything queued on the device has reported
+    hipLaunchKernelGGL(flags_sweep_kernel, dim3(1), dim3(256), 0, nullptr, fp.dev, kFlagSlots, fp.host_dev);
+    ADK_HIP_CHECK(hipGetLastError());
+    ADK_HIP_CHECK(hipStreamSynchronize(nullptr));
+    *acc |= fp.host[0];
+    return ADK_OK;
+}
 
 extern "C" int adk_debug_flags(int32_t* out) {
-    // OR of the flag words of every device this library has launched on (plus the current one); each is fetched and cleared
-    // by one atomicExch after everything queued on that device has finished
-    static int* scratch[kMaxDevices] = {};
+    // OR of the flag words of every device this library has launched on (plus the current one): per device ONE sweep kernel that
+    // exchanges every program slot and the device word for 0, after everything queued on that device has finished
+    static std::mutex dbg_mu;                          // slot 0 of the host mirror is this function's: one caller at a time
+    std::lock_guard<std::mutex> lk(dbg_mu);
     int all = 0;
     const int here = current_device();
     for (int d = 0; d < kMaxDevices; ++d) {
-        if (!g_flag_ptr[d] && d != here) continue;
+        if (!g_flag_ptr[d] && !g_pool[d].dev && d != here) continue;
         DeviceGuard guard(d);
-        if (!scratch[d]) ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scratch[d]), sizeof(int)));
-        ADK_HIP_CHECK(hipDeviceSynchronize());
-        hipLaunchKernelGGL(flags_fetch_clear_kernel, dim3(1), dim3(1), 0, nullptr, scratch[d]);
-        ADK_HIP_CHECK(hipGetLastError());
-        int v = 0;
-        ADK_HIP_CHECK(hipMemcpy(&v, scratch[d], sizeof(int), hipMemcpyDeviceToHost));
-        all |= v;
-        const int rc = fetch_clear_program_flags(d, &all);       // programs report to words of their own (adk_program_flags)
+        const int rc = flag_pool_fetch_all(d, &all);
         if (rc != ADK_OK) return rc;
     }
     if (out) *out = all;
     return ADK_OK;
 }
+
+}  // namespace adk

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -75,6 +75,8 @@ SYMBOLS = {
     "adk_program_reset": (C.c_int, [_vp, _vp]),
     "adk_program_flags": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
     "adk_program_rewind": (C.c_int, [_vp, _i32]),
+    "adk_program_get_fresh": (C.c_int, [_vp]),
+    "adk_program_set_fresh": (C.c_int, [_vp, _i32]),
     "adk_program_get_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "adk_program_set_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "adk_program_describe_op": (C.c_int, [_vp, _i32, _i32, C.c_char_p, _i32]),
@@ -159,9 +161,10 @@ def raise_for_flags(v, where=""):
         raise ValueError(pre + "an index that is not a code of its stage was packed (wire format)")
     if v & FLAG_F16_OVERFLOW:
         raise NativeError(pre + "a split-f16 conv produced non-finite values: an operand beyond the f16 range "
-                                "(|v| > 65504) or non-finite input; results since the last check are invalid "
-                                "(synchronous callers recover automatically -- guard=True, the default of AudioDec; an asynchronous "
-                                "pipeline that runs into this should use the exact-f32 kernels: ADK_SPLIT16=0 / set_split16(False))")
+                                "(|v| > 65504) or non-finite input; results since the last check are invalid.  A generator with its "
+                                "guard on (the default of AudioDec, streaming and offline programs alike) repeats such a step on the "
+                                "exact-f32 kernels by itself and does not get here; this is the report for unguarded steps (guard=False / "
+                                "ADK_GUARD=0: asynchronous pipelines) -- run those on the exact-f32 kernels: ADK_SPLIT16=0 / set_split16(False)")
     if v & FLAG_STREAMK_TIMEOUT:
         raise NativeError(pre + "a stream-K conv workgroup timed out waiting for a partial tile; results since the "
                                 "last check are invalid")

@@ -546,6 +546,9 @@ class HipProgram:
             raise native.NativeError("the exact-f32 twin has a different state layout")
         twin.arena.copy_(self.arena)
         twin.set_cursors(self.cursors())
+        # "fresh" (no step since reset) decides whether the offline lowering's history replicate runs: the twin repeats the step
+        # in the state this program was in before it (adk_program_rewind put the bit back)
+        native.check(self.lib.adk_program_set_fresh(twin.h, self.lib.adk_program_get_fresh(self.h)), "adk_program_set_fresh")
         if self.workgroups:
             twin.set_workgroups(self.workgroups)
         mine = dict(self.__dict__)

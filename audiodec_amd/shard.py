@@ -85,3 +85,14 @@ def max_over_ranks(value, device):
     if w > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value, device):
+    """One float per rank, on every rank (bench.py: each rank's own frames/s beside the whole-job figure)."""
+    rank, w = world()
+    if w == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    bufs = [torch.empty_like(t) for _ in range(w)]
+    dist.all_gather(bufs, t)
+    return [float(b.item()) for b in bufs]

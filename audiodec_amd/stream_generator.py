@@ -85,13 +85,17 @@ class _StreamBase:
         return self
 
     def set_guard(self, on=True):
-        """guard=True (default): every program step is followed by a check of the program's device flag word (one stream
+        """(on=None: keep the current setting -- the constructor's, i.e. ADK_GUARD, default on.)
+        guard=True (default): every program step is followed by a check of the program's device flag word (one stream
         synchronisation per step).  A split-f16 step that met an operand beyond the f16 range is REPEATED on the exact-f32
         kernels -- ring cursors rewound, state carried over, same inputs: exact, because a step only reads history rows earlier
         steps wrote -- and the program stays on them from then on (a warning says so); any other device-side failure raises
         here, at the step that caused it.  guard=False: nothing synchronises; failures surface at the caller's next
-        native.raise_on_device_flags() (asynchronous multi-stream pipelines: bench.py)."""
-        self.guard = bool(on)
+        native.raise_on_device_flags() (asynchronous multi-stream pipelines: bench.py).  Streaming and offline programs
+        (set_offline) are repaired alike: the rewind also restores the "first step after reset" bit the offline lowering's
+        replication pad depends on."""
+        if on is not None:
+            self.guard = bool(on)
         return self
 
     def set_split16(self, on=True):
@@ -140,7 +144,7 @@ class _StreamBase:
         if not self.guard:
             return
         fl = prog.flags()
-        if fl & native.FLAG_F16_OVERFLOW and prog.split16 and prog.twin_builder is not None and not prog.offline:
+        if fl & native.FLAG_F16_OVERFLOW and prog.split16 and prog.twin_builder is not None:
             import warnings
             prog.rewind(frames)
             prog.demote()
@@ -403,7 +407,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
         return zq
 
     # ---- bit-packed transport (audiodec_amd/wire.py; the reference has no wire format) ----
-    def pack(self, idx, check=False):
+    def pack(self, idx, check=True):
         """Emitted indices -> uint8 payload (B, T, n_q*bits/8): 10 bytes per frame for 8 x 1024 codes."""
         from . import wire
         return wire.pack_codes(idx.to(self._dev()), self.size, check)

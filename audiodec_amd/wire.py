@@ -22,14 +22,15 @@ def frame_bytes(n_q, codebook_size):
     return (n_q * code_bits(codebook_size) + 7) // 8
 
 
-def pack_codes(idx, codebook_size=1024, check=False):
+def pack_codes(idx, codebook_size=1024, check=True):
     """idx (n_q, T) or (n_q, B, T) int64 on a HIP device -> uint8 payload (B, T, frame_bytes).
 
-    Asynchronous by default: an index that is not a code of its stage is packed as code 0 and recorded in the sticky
-    device flags, which the caller's next synchronisation point turns into the exception (native.raise_on_device_flags:
-    streamer ticks, demoFile, the offline drivers).  check=True does that here: it SYNCHRONISES the device and raises on
-    any pending device flag (not only this call's) -- for one-off calls whose payload leaves the device right away, never
-    inside a real-time tick."""
+    check=True (the public default): the call SYNCHRONISES the device and raises on any pending device flag -- an index
+    that is not a code of its stage (ValueError; it would otherwise travel as code 0), or anything an earlier asynchronous
+    launch reported -- so a payload this function returns is safe to ship.  check=False is for real-time tick paths
+    that keep the device running (batched_streamer passes it): a bad index is then packed as code 0 and only recorded in
+    the sticky device flags, which the caller's next synchronisation point turns into the exception
+    (native.raise_on_device_flags: streamer ticks, demoFile, the offline drivers)."""
     dev = native.require_gpu(idx.device)
     if idx.dim() == 2:
         idx = idx.unsqueeze(1)

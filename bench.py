@@ -29,20 +29,24 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak; a split-f16 product sum issues 3 of them
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_MARKER_N = 7654321                         # --pmc-markers: element count of the marker launches
-PMC_TRAFFIC_FILE = "r3_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, pipelined schedule (tools/profile_round.sh)
-STEADY_STATS_FILE = "r3_kernel_stats_steady.csv"   # rocprofv3 --kernel-trace over the timed steps of the same schedule (tools/trace_summary.py)
+PMC_TRAFFIC_FILE = "r4_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, pipelined schedule (tools/profile_round.sh)
+STEADY_STATS_FILE = "r4_kernel_stats_steady.csv"   # rocprofv3 --kernel-trace over the timed steps of the same schedule (tools/trace_summary.py)
+SERIAL_STATS_FILE = "r4_kernel_stats_serial.csv"   # ... of `bench.py --serial` (one HIP stream, nothing else on the chip)
 PMC_TRAFFIC_SCRIPT = "tools/profile_round.sh"
 
-def build_audiodec(root, device, streams, max_frames, sd_bcast=False):
+def build_audiodec(root, device, streams, max_frames, model=None, guard=False):
     from audiodec_amd import synth
     from audiodec_amd.audiodec import AudioDec, assign_model
+    if model is not None and model != MODEL:
+        synth.write_model(root, model, SEED)        # (MODEL's checkpoints were written by main() from the broadcast state dicts)
     cwd = os.getcwd()
     os.chdir(root)
     try:
-        sr, enc_ckpt, dec_ckpt = assign_model(MODEL)
-        # guard=False: the pipeline keeps three batches in flight, nothing may synchronise per step; device-side failures are
-        # collected at the end of the run (adk_debug_flags must read 0)
-        ad = AudioDec(tx_device=device, rx_device=device, num_streams=streams, max_frames=max_frames, guard=False)
+        sr, enc_ckpt, dec_ckpt = assign_model(model or MODEL)
+        # guard=False (the headline): the pipeline keeps three batches in flight, nothing may synchronise per step; device-side
+        # failures are collected at the end of the run (adk_debug_flags must read 0).  guard=True is AudioDec's default: every
+        # program step is checked on the device (one stream synchronisation each) -- timed as the `guarded` leg
+        ad = AudioDec(tx_device=device, rx_device=device, num_streams=streams, max_frames=max_frames, guard=guard)
         import contextlib, io
         with contextlib.redirect_stdout(io.StringIO()):
             ad.load_transmitter(enc_ckpt)
@@ -127,21 +131,51 @@ class TxRxPipeline:
             cur.wait_stream(s)
 
 
-def op_profile(ad, xs, streams, n_steps, fps=1):
-    """Per-op HIP-event durations (events recorded on the launch stream by the C++ runner)."""
+def _programs_of(ad):
     progs = {"encoder": ad.tx_encoder._encoder()}
     stages = ad.decoder._decoder_stages() if hasattr(ad.decoder, "_decoder_stages") else [ad.decoder._decoder()]
     for i, pr in enumerate(stages):
         progs["decoder" if i == 0 else f"decoder{i}"] = pr
-    for p in progs.values():
-        p.set_profiling(True)
+    return progs
+
+
+def op_profile(ad, xs, streams, n_steps, fps=1, pipe=None, burst=7, at=3):
+    """Per-op HIP-event durations (events recorded on the launch stream by the C++ runner around every op).
+
+    pipe=None: the SERIAL schedule -- one HIP stream, one batch at a time, nothing else on the chip.
+    pipe=TxRxPipeline: the schedule `value` is timed in -- n_steps bursts of `burst` pipeline steps, of which step `at` (batches before
+    AND behind it in flight on the other HIP streams) records the events; a program's events are re-recorded by every profiled step,
+    so only one step per burst can be read, and reading needs a device synchronisation, which is why this is a region of its own
+    behind the timed one and not the timed region itself."""
+    progs = _programs_of(ad)
     acc = {k: np.zeros(p.n_ops) for k, p in progs.items()}
-    for i in range(n_steps):
-        step(ad, xs[i % len(xs)])
-        for k, p in progs.items():
-            acc[k] += np.asarray(p.last_op_ms())
-    for p in progs.values():
-        p.set_profiling(False)
+    if pipe is None:
+        for p in progs.values():
+            p.set_profiling(True)
+        for i in range(n_steps):
+            step(ad, xs[i % len(xs)])
+            for k, p in progs.items():
+                acc[k] += np.asarray(p.last_op_ms())
+        for p in progs.values():
+            p.set_profiling(False)
+    else:
+        for i in range(n_steps):
+            torch.cuda.synchronize()
+            pipe.enter()
+            for j in range(burst):
+                if j == at:
+                    for p in progs.values():
+                        p.set_profiling(True)
+                pipe.step(xs[(i * burst + j) % len(xs)])
+                if j == at:
+                    for p in progs.values():
+                        p.set_profiling(False)          # (a flag of the host-side runner: the recorded events stay as they are)
+            pipe.exit()
+            torch.cuda.synchronize()
+            for k, p in progs.items():
+                p.set_profiling(True)
+                acc[k] += np.asarray(p.last_op_ms())
+                p.set_profiling(False)
     rows = []
     for k, p in progs.items():
         for i in range(p.n_ops):
@@ -223,10 +257,11 @@ def pmc_traffic(dom):
     return (round(num / den) if den else None), stale
 
 
-def rocprof_duration(dom):
-    """Average duration (us) of kernel `dom` over the timed steps of the pipelined schedule, from the committed rocprofv3 kernel trace
-    (profiles/STEADY_STATS_FILE; the dispatch's own start/end, no launch gap, no event record), and whether that capture is stale."""
-    rows, meta = _profile_csv(STEADY_STATS_FILE)
+def rocprof_duration(dom, stats_file=None):
+    """Average duration (us) of kernel `dom` over the timed steps of the bench, from a committed rocprofv3 kernel trace (profiles/
+    STEADY_STATS_FILE: the pipelined schedule, SERIAL_STATS_FILE: `--serial`; the dispatch's own start/end, no launch gap, no event
+    record), and whether that capture is stale."""
+    rows, meta = _profile_csv(stats_file or STEADY_STATS_FILE)
     sub = _rocprof_name(dom)
     if rows is None or sub is None:
         return None, None
@@ -242,17 +277,21 @@ FUSED = "(fused into the previous op)"
 
 
 def launches_of(rows, streams, fps=1):
-    """Per-op rows -> per-LAUNCH records: an op the runner folded into its predecessor's launch (a residual unit or a whole
-    residual chain run as one kernel) adds its flops and its event time to that launch.  Algorithmic bytes of a fused launch:
-    chain input (new rows + history) + every conv's weights + the history rows the later convs read from / leave in their state
-    rings + the chain output, once each -- what no implementation of the streaming recurrence can avoid moving."""
+    """Per-op rows -> per-LAUNCH records.  An op the runner folded into its predecessor's launch (a residual unit or a whole
+    residual chain run as one kernel) adds its flops to that launch.  Time: the runner records one event behind every op, so a launch
+    that covers n ops is followed by n events back to back; the kernel sits between the event in front of the head op and the one
+    behind it -- `ms` = the HEAD op's event time (kernel + ONE event record); the n - 1 further "durations" are event records with
+    no kernel in between, kept as `ms_events_only` (what an event record costs on this stream, measured in the run).
+    Algorithmic bytes of a fused launch: chain input (new rows + history) + every conv's weights + the history rows the later convs
+    read from / leave in their state rings + the chain output, once each -- what no implementation of the streaming recurrence can
+    avoid moving."""
     out = []
     for r in rows:
         if r["kernel"] == FUSED and out and out[-1]["prog"] == r["prog"]:
             L = out[-1]
-            L["ms"] += r["ms"]; L["flops"] += r["flops"]; L["ops"].append(r)
+            L["ms_events_only"] += r["ms"]; L["flops"] += r["flops"]; L["ops"].append(r)
             continue
-        out.append(dict(prog=r["prog"], name=r["name"], kernel=r["kernel"], ms=r["ms"], flops=r["flops"], bytes=r["bytes"], ops=[r], op=r["op"]))
+        out.append(dict(prog=r["prog"], name=r["name"], kernel=r["kernel"], ms=r["ms"], ms_events_only=0.0, flops=r["flops"], bytes=r["bytes"], ops=[r], op=r["op"]))
     for L in out:
         if len(L["ops"]) > 1:
             ops = [q["op"] for q in L["ops"]]
@@ -273,75 +312,129 @@ def mean_launch_bytes(launches, dom):
     return round(sum(sel) / len(sel)) if sel else None
 
 
-def roofline_from(rows, streams, fps=1, split16=False):
-    launches = launches_of(rows, streams, fps)
-    # What a per-op HIP-event pair costs by itself: the ops a launch swallowed ("fused into the previous op") are bracketed by two
-    # event records with NO kernel in between, so their "duration" is the overhead every per-op figure carries (~4.7 us).  It is
-    # measured here, in the run, and subtracted: avg_launch_us is the kernel, avg_launch_us_with_event what the events said.
+def event_record_ms(rows):
+    """What ONE event record costs on the launch stream: median "duration" of the ops that ran inside another op's launch (two event
+    records with no kernel in between).  0 when the step has no such op."""
     gaps = [r["ms"] for r in rows if r["kernel"] == FUSED]
-    ev_ms = float(np.median(gaps)) if gaps else 0.0
-    for L in launches:
-        L["ms_raw"] = L["ms"]
-        L["ms"] = max(L["ms"] - ev_ms * len(L["ops"]), 0.25 * L["ms"])
+    return float(np.median(gaps)) if gaps else 0.0
+
+
+def kernel_table(rows, streams, fps=1):
+    """{kernel: {ms, ms_est, flops, launches, bytes}} over one step.  ms = the raw HIP-event time of its launches (each includes ONE event
+    record); ms_est = the same minus ONE measured event record per launch (an ESTIMATE of the kernels alone, floored at half the raw)."""
+    launches = launches_of(rows, streams, fps)
+    ev = event_record_ms(rows)
     by = {}
-    for r in launches:
-        d = by.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
-        d["ms"] += r["ms"]; d["flops"] += r["flops"]; d["launches"] += 1; d["bytes"] += r.get("bytes", 0.0)
-    dom = max(by, key=lambda k: by[k]["ms"])
-    d = by[dom]
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    for L in launches:
+        d = by.setdefault(L["kernel"], dict(ms=0.0, ms_est=0.0, flops=0.0, launches=0, bytes=0.0))
+        d["ms"] += L["ms"]; d["ms_est"] += max(L["ms"] - ev, 0.5 * L["ms"]); d["flops"] += L["flops"]; d["launches"] += 1; d["bytes"] += L.get("bytes", 0.0)
+    return launches, by, ev
+
+
+def _frac(flops, ms, peak):
+    return round(flops / (ms * 1e-3) / 1e12 / peak, 4) if ms and ms > 0 else None
+
+
+def roofline_from(rows_serial, streams, fps=1, split16=False, rows_pipe=None):
+    """The roofline objects of the JSON line.  rows_serial: per-op events of the serial schedule; rows_pipe: of the pipelined schedule
+    (None for --serial runs).  The dominant kernel is picked by its share of the event time in the schedule `value` is timed in; `frac`
+    is priced on THAT schedule's live events (raw: every launch's time includes one event record), with the serial figure, the
+    minus-one-event-record estimates and the dispatch durations of the committed rocprofv3 kernel traces of both schedules beside it."""
+    launches_s, by_s, ev_s = kernel_table(rows_serial, streams, fps)
+    if rows_pipe is not None:
+        launches_p, by_p, ev_p = kernel_table(rows_pipe, streams, fps)
+    else:
+        launches_p, by_p, ev_p = launches_s, by_s, ev_s
+    dom = max(by_p, key=lambda k: by_p[k]["ms"])
+    d, ds = by_p[dom], by_s[dom]
     # algorithmic (f32-equivalent) flops against the matrix-core peak of the instruction the kernel issues: the exact-f32
     # MFMA, or -- for the split-f16 kernels -- the dense f16 MFMA peak divided by the 3 instructions per product sum
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     traffic, stale = pmc_traffic(dom)
-    rp_us, rp_stale = rocprof_duration(dom)
-    raw_ms = sum(L["ms_raw"] for L in launches if L["kernel"] == dom)
+    rp_us, rp_stale = rocprof_duration(dom, STEADY_STATS_FILE)
+    rs_us, rs_stale = rocprof_duration(dom, SERIAL_STATS_FILE)
+    fpl = d["flops"] / d["launches"]
+    sched = "pipelined" if rows_pipe is not None else "serial"
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_stale": stale,
-            "algorithmic_bytes_per_launch": mean_launch_bytes(launches, dom),
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "frac_schedule": sched,
+            "frac_pipelined": _frac(d["flops"], d["ms"], peak) if rows_pipe is not None else None,
+            "frac_serial": _frac(ds["flops"], ds["ms"], peak),
+            "frac_pipelined_minus_event_estimate": _frac(d["flops"], d["ms_est"], peak) if rows_pipe is not None else None,
+            "frac_serial_minus_event_estimate": _frac(ds["flops"], ds["ms_est"], peak),
+            "frac_rocprof_pipelined": _frac(fpl, rp_us * 1e-3, peak) if rp_us else None,
+            "frac_rocprof_serial": _frac(fpl, rs_us * 1e-3, peak) if rs_us else None,
+            "traffic": traffic, "traffic_stale": stale,
+            "algorithmic_bytes_per_launch": mean_launch_bytes(launches_p, dom),
             "traffic_note": "both are means per launch over all launches of this kernel in the timed steps: traffic = FETCH_SIZE x2 + "
                             f"WRITE_SIZE from the committed PMC passes over this bench in the SAME pipelined schedule (profiles/{PMC_TRAFFIC_FILE}, "
                             f"{PMC_TRAFFIC_SCRIPT}, steady-state launches picked out by --pmc-markers; PMC counters cannot be read from inside the "
                             "bench process), not collected live -- traffic_stale says whether the kernels were rebuilt from other sources since; "
                             "algorithmic = input rows incl. history + weights + outputs (+ residual / state rows), once each",
             "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-            "avg_launch_us_with_event": round(1e3 * raw_ms / d["launches"], 2), "event_pair_overhead_us": round(1e3 * ev_ms, 2),
-            "avg_launch_us_rocprof": rp_us, "rocprof_stale": rp_stale,
-            "duration_note": "avg_launch_us = per-op HIP-event time on the launch stream minus the cost of the event pair itself, which this run "
-                             "measures on the ops that ran inside another op's launch (two records, no kernel in between); avg_launch_us_rocprof = the "
-                             f"same kernel's dispatch duration in the committed rocprofv3 kernel trace of the timed steps (profiles/{STEADY_STATS_FILE}; "
-                             "there the three programs run concurrently, so a kernel shares the chip -- it is not expected to be shorter)",
-            "flops_per_launch": d["flops"] / d["launches"], "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by.values()), 3),
-            "launches_per_step_all_kernels": len(launches)}
+            "avg_launch_us_serial": round(1e3 * ds["ms"] / ds["launches"], 2),
+            "event_record_us": round(1e3 * ev_p, 2), "event_record_us_serial": round(1e3 * ev_s, 2),
+            "avg_launch_us_rocprof_pipelined": rp_us, "avg_launch_us_rocprof_serial": rs_us,
+            "rocprof_stale": None if rp_stale is None and rs_stale is None else bool(rp_stale or rs_stale),
+            "duration_note": "avg_launch_us / frac: live HIP events on the launch stream in the PIPELINED schedule (three HIP streams, batches in flight in "
+                             "front of and behind the profiled one -- the schedule `value` is timed in); every figure includes ONE event record per launch "
+                             "(event_record_us, measured in the run on the ops that ran inside another op's launch).  *_serial: the same on one HIP stream with "
+                             "nothing else on the chip.  *_minus_event_estimate: ONE measured event record subtracted per launch -- an estimate.  "
+                             f"*_rocprof_*: flops_per_launch over the dispatch duration of this kernel in the committed rocprofv3 kernel traces of the timed "
+                             f"steps (profiles/{STEADY_STATS_FILE} pipelined, profiles/{SERIAL_STATS_FILE} serial; tools/profile_round.sh) -- reproducible from "
+                             "those files alone; rocprof_stale says whether the kernels were rebuilt since",
+            "flops_per_launch": fpl, "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by_p.values()), 3),
+            "launches_per_step_all_kernels": len(launches_p)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler) -- since round 3 the launch
     # that contains it also runs the 1x1 conv_out (192 -> 64) in front of it (conv_ou16): bytes and time are those of THAT launch
-    ct = [L for L in launches if any(q["name"] == "upsamples.3" for q in L["ops"])]
-    roof_ct = None
-    if ct:
-        L = ct[0]
-        up = [q for q in L["ops"] if q["name"] == "upsamples.3"][0]
-        c = up["op"].conv
-        t_in = up["op"].rate_out * fps
-        cin, cout, s = c.cin_g, c.cout_real, c.up
-        fused = len(L["ops"]) > 1
-        if fused:
-            c1 = L["ops"][0]["op"].conv                      # the 1x1 conv: reads cin1 channels per step, the 64-channel tensor stays on chip
-            bytes_alg = 4.0 * (c1.cin_g * t_in + cin + cout * t_in * s) * streams + 4.0 * (c1.cin_g * c1.cout_g + cin * cout * 2 * s)
-            what = f"{L['kernel']} blocks.2.conv_out (1x1 {c1.cin_g}->{c1.cout_g}) + LeakyReLU + upsamples.3 (ConvTranspose1d {cin}->{cout} s{s} + bias), one launch"
-        else:
-            bytes_alg = 4.0 * (cin * (t_in + 1) + cout * t_in * s) * streams + 4.0 * cin * cout * 2 * s
-            what = L["kernel"] + " upsamples.3 (LeakyReLU+ConvTranspose1d 64->32 s3 +bias)"
-        gbs = bytes_alg / (L["ms"] * 1e-3) / 1e9
-        rp_us, rp_stale = rocprof_duration(L["kernel"])
-        roof_ct = {"kernel": what, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                   "traffic": pmc_traffic(L["kernel"])[0], "avg_launch_us": round(1e3 * L["ms"], 2), "avg_launch_us_with_event": round(1e3 * L["ms_raw"], 2),
-                   "avg_launch_us_rocprof": rp_us, "rocprof_stale": rp_stale, "bytes_per_launch": bytes_alg, "fused_with_conv_out": fused,
-                   "fp32_tflops": round(L["flops"] / (L["ms"] * 1e-3) / 1e12, 2),
-                   "how": "HIP events around the launch in the serial per-op profile (one HIP stream, nothing else on the chip) minus the measured cost of "
-                          "the event pair; avg_launch_us_rocprof is the dispatch duration inside the concurrent three-stream schedule"}
-    kernels = {k: {"ms_per_step": round(v["ms"], 4), "launches": v["launches"],
-                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0} for k, v in by.items()}
+    roof_ct = convtr_roofline(launches_s, launches_p if rows_pipe is not None else None, ev_s, ev_p, streams, fps)
+    kernels = {k: {"ms_per_step": round(v["ms"], 4), "ms_per_step_serial": round(by_s[k]["ms"], 4) if k in by_s else None, "launches": v["launches"],
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0} for k, v in by_p.items()}
     return roof, roof_ct, kernels
+
+
+def convtr_roofline(launches_s, launches_p, ev_s, ev_p, streams, fps):
+    """HBM roofline of the launch that contains upsamples.3 (the north-star's named kernel), from per-launch event records."""
+    ct = [L for L in launches_s if any(q["name"] == "upsamples.3" for q in L["ops"])]
+    if not ct:
+        return None
+    L = ct[0]
+    up = [q for q in L["ops"] if q["name"] == "upsamples.3"][0]
+    c = up["op"].conv
+    t_in = up["op"].rate_out * fps
+    cin, cout, s = c.cin_g, c.cout_real, c.up
+    fused = len(L["ops"]) > 1
+    if fused:
+        c1 = L["ops"][0]["op"].conv                      # the 1x1 conv: reads cin1 channels per step, the 64-channel tensor stays on chip
+        bytes_alg = 4.0 * (c1.cin_g * t_in + cin + cout * t_in * s) * streams + 4.0 * (c1.cin_g * c1.cout_g + cin * cout * 2 * s)
+        what = f"{L['kernel']} blocks.2.conv_out (1x1 {c1.cin_g}->{c1.cout_g}) + LeakyReLU + upsamples.3 (ConvTranspose1d {cin}->{cout} s{s} + bias), one launch"
+    else:
+        bytes_alg = 4.0 * (cin * (t_in + 1) + cout * t_in * s) * streams + 4.0 * cin * cout * 2 * s
+        what = L["kernel"] + " upsamples.3 (LeakyReLU+ConvTranspose1d 64->32 s3 +bias)"
+    gbs = lambda ms: round(bytes_alg / (ms * 1e-3) / 1e9, 1) if ms and ms > 0 else None
+    fr = lambda ms: round(bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms and ms > 0 else None
+    ms_s = L["ms"]
+    ms_p = None
+    if launches_p is not None:
+        lp = [q for q in launches_p if any(o["name"] == "upsamples.3" for o in q["ops"])]
+        ms_p = lp[0]["ms"] if lp else None
+    ms_main = ms_p if ms_p is not None else ms_s
+    rp_us, rp_stale = rocprof_duration(L["kernel"], STEADY_STATS_FILE)
+    rs_us, rs_stale = rocprof_duration(L["kernel"], SERIAL_STATS_FILE)
+    return {"kernel": what, "bound": "hbm", "achieved": gbs(ms_main), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr(ms_main),
+            "frac_schedule": "pipelined" if ms_p is not None else "serial",
+            "frac_pipelined": fr(ms_p), "frac_serial": fr(ms_s),
+            "frac_serial_minus_event_estimate": fr(max(ms_s - ev_s, 0.5 * ms_s)),
+            "frac_rocprof_pipelined": fr(rp_us * 1e-3) if rp_us else None, "frac_rocprof_serial": fr(rs_us * 1e-3) if rs_us else None,
+            "traffic": pmc_traffic(L["kernel"])[0], "avg_launch_us": round(1e3 * ms_main, 2), "avg_launch_us_serial": round(1e3 * ms_s, 2),
+            "event_record_us_serial": round(1e3 * ev_s, 2),
+            "avg_launch_us_rocprof_pipelined": rp_us, "avg_launch_us_rocprof_serial": rs_us,
+            "rocprof_stale": None if rp_stale is None and rs_stale is None else bool(rp_stale or rs_stale),
+            "bytes_per_launch": bytes_alg, "fused_with_conv_out": fused,
+            "fp32_tflops": round(L["flops"] / (ms_main * 1e-3) / 1e12, 2),
+            "how": "live HIP events around the launch (each figure includes one event record): frac / avg_launch_us in the pipelined three-stream "
+                   "schedule, *_serial on one HIP stream with nothing else on the chip; *_minus_event_estimate subtracts one measured event record; "
+                   "*_rocprof_* = bytes_per_launch over the dispatch duration in the committed rocprofv3 kernel traces of the same schedules"}
 
 
 def convtr_standalone(dev, sd_dec, B, fps, split16, iters=300):
@@ -360,6 +453,49 @@ def convtr_standalone(dev, sd_dec, B, fps, split16, iters=300):
     torch.cuda.synchronize()
     us = m.time_kernel(t_in, iters)            # the launch loop and its HIP events run inside the library (no Python per launch)
     return us, m.last_kernel
+
+
+def convtr_t5(root, dev, sd_dec, B, split16, fps=5):
+    """Secondary roofline of the north-star's named kernel at the reference streamer's DEFAULT chunk: demoStream.py:28 frame_size = 1500
+    samples = 5 hops per call (T = 5), where one launch of upsamples.3 moves 5x the rows of the headline's single-frame step.  A second
+    model (max_frames = 5) is profiled per op on one HIP stream; the fused conv_out + upsamples.3 launch takes at most 128 input steps per
+    stream, so at 500 the transposed conv runs as its own streaming launch (conv_up16), which is what this line prices."""
+    ad5 = build_audiodec(root, dev, B, fps)
+    from audiodec_amd import synth
+    xs5 = [torch.from_numpy(np.stack([synth.synth_audio(SEED + 500 + j, s, HOP * fps) for s in range(B)]))[:, None, :].to(dev) for j in range(2)]
+    for i in range(4):
+        step(ad5, xs5[i % 2])
+    torch.cuda.synchronize()
+    rows5 = op_profile(ad5, xs5, B, 6, fps)
+    launches, by, ev = kernel_table(rows5, B, fps)
+    res = convtr_roofline(launches, None, ev, ev, B, fps) or {}
+    for k in ("frac_pipelined", "frac_rocprof_pipelined", "frac_rocprof_serial", "avg_launch_us_rocprof_pipelined", "avg_launch_us_rocprof_serial", "rocprof_stale", "traffic"):
+        res.pop(k, None)                   # (the committed traces / PMC passes are of the single-frame headline schedule)
+    us, kname = convtr_standalone(dev, sd_dec, B, fps, split16)
+    b_alone = 4.0 * (64 * (100 * fps + 1) + 32 * 300 * fps) * B + 4.0 * 64 * 32 * 6
+    res["transposed_conv_alone"] = {"kernel": kname, "avg_launch_us": round(us, 2), "bytes_per_launch": b_alone,
+                                    "achieved": round(b_alone / (us * 1e-6) / 1e9, 1), "frac": round(b_alone / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "how": f"300 back-to-back launches of upsamples.3 alone, {B} streams x {100 * fps} input steps, HIP events inside the library"}
+    pipe5 = TxRxPipeline(ad5, dev)
+    n = 20
+    pipe5.enter()
+    for i in range(6):
+        pipe5.step(xs5[i % 2])
+    pipe5.exit()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe5.enter()
+    for i in range(n):
+        pipe5.step(xs5[i % 2])
+    pipe5.exit()
+    torch.cuda.synchronize()
+    e = time.perf_counter() - t0
+    res["frames_per_step_per_stream"] = fps
+    res["pipeline_frames_per_s"] = round(B * fps * n / e, 1)
+    res["pipeline_ms_per_step"] = round(1e3 * e / n, 4)
+    res["what"] = (f"the same workload at {fps} frames per stream per call (demoStream.py:28: frame_size 1500 = 5 hops, the reference streamer's default "
+                   "chunk); serial per-op HIP events + the kernel alone; NOT the headline configuration (1 frame per call)")
+    return res
 
 
 def cpu_baseline(budget_s=12.0, threads=4, stack_calls=0):
@@ -434,13 +570,15 @@ def _widen(o, batch):
     return o
 
 
-def self_check(root, dev, B, fps, serial, steps=2):
-    """Parity of the TIMED configuration: a fresh AudioDec with the same stream count, arithmetic, lowering and schedule
+def self_check(root, dev, B, fps, serial, steps=2, model=None, decode=True):
+    """Parity of a TIMED configuration: a fresh AudioDec with the same stream count, arithmetic, lowering and schedule
     object runs `steps` batches; latent, RVQ indices and waveform are compared with the CPU oracle (the checker, never the
-    thing measured).  North-star tolerances: waveform <= 1e-4 max-abs, indices bit-exact."""
+    thing measured).  North-star tolerances: waveform <= 1e-4 max-abs, indices bit-exact.  model / decode: the headline's
+    (vctk_v1, whole path) by default; extra_configs passes BASELINE configs 2 (vctk_sym encoder + RVQ only) and 3 (vctk_sym)."""
     from audiodec_amd import synth, configs
     from oracle import audiodec_oracle as O
-    ad = build_audiodec(root, dev, B, fps)
+    model = model or MODEL
+    ad = build_audiodec(root, dev, B, fps, model=model)
     pipe = None if serial else TxRxPipeline(ad, dev)
     xs = [torch.from_numpy(np.stack([synth.synth_audio(SEED + 1000 + j, s, HOP * fps) for s in range(B)]))[:, None, :].to(dev)
           for j in range(steps)]
@@ -452,11 +590,11 @@ def self_check(root, dev, B, fps, serial, steps=2):
             ys.append(pipe.step(x)); zs.append(pipe.last_z); idxs.append(pipe.last_idx)
         else:
             z = ad.tx_encoder.encode(x); idx = ad.tx_encoder.quantize(z)
-            ys.append(ad.decoder.decode(ad.rx_encoder.lookup(idx))); zs.append(z); idxs.append(idx)
+            ys.append(ad.decoder.decode(ad.rx_encoder.lookup(idx)) if decode else None); zs.append(z); idxs.append(idx)
     if pipe:
         pipe.exit()
     torch.cuda.synchronize()
-    _, enc_tag, _, dec_tag, _ = configs.alias(MODEL)
+    _, enc_tag, _, dec_tag, _ = configs.alias(model)
     mt_d, _, pd = configs.experiment(dec_tag)
     _, _, pe = configs.experiment(enc_tag)
     t0 = time.perf_counter()
@@ -472,12 +610,12 @@ def self_check(root, dev, B, fps, serial, steps=2):
         for j in range(steps):
             oz = tx.encode(xs[j].cpu())
             oi, om = tx.quantize(oz, return_margin=True)
-            oy = dec.decode(tx.lookup(oi))
+            oy = dec.decode(tx.lookup(oi)) if decode else None
             gi = idxs[j].cpu().reshape(oi.shape)
             bad = (gi != oi)
             clean &= ~bad.any(0).any(-1)                          # a stream whose codes differ decodes a different signal from
             dz = max(dz, float((zs[j].cpu() - oz).abs().max()))   # then on: its waveform is compared up to the flip only
-            if bool(clean.any()):
+            if decode and bool(clean.any()):
                 dy = max(dy, float((ys[j].cpu() - oy)[clean].abs().max()))
             for b_, t_ in bad.any(0).nonzero().tolist():          # the first flipped stage of a frame is the decision that differed
                 q_ = int(bad[:, b_, t_].nonzero()[0])
@@ -490,7 +628,8 @@ def self_check(root, dev, B, fps, serial, steps=2):
             decisions += int(oi.numel())
             min_margin = min(min_margin, float(om.min()))
     ok = dz < 1e-4 and dy < 1e-4 and unexplained == 0
-    return {"ok": ok, "streams": B, "steps": steps, "max_abs_dz": dz, "max_abs_dy": dy, "indices_equal": flips == 0,
+    return {"ok": ok, "model": model, "path": "encode -> RVQ -> lookup -> decode" if decode else "encode -> RVQ", "streams": B, "steps": steps,
+            "max_abs_dz": dz, "max_abs_dy": dy if decode else None, "indices_equal": flips == 0,
             "frames_with_flipped_indices": flips, "flip_margins": flip_margins,
             "unexplained_flips": int(unexplained), "streams_compared_to_the_end": int(clean.sum()), "rvq_decisions": decisions, "min_reference_top2_margin": min_margin,
             "tolerance": {"waveform_max_abs": 1e-4, "indices": "bit-exact"}, "oracle_cpu_s": round(time.perf_counter() - t0, 1),
@@ -498,8 +637,14 @@ def self_check(root, dev, B, fps, serial, steps=2):
                     "vs the CPU oracle (oracle/audiodec_oracle.py)"}
 
 
-def extra_configs(root, dev, steps=100, warmup=10):
-    """SURVEY.md 8(d) configs 1-4 on this GPU in the arithmetic of the run (the headline is config 5's per-GPU share)."""
+def extra_configs(root, dev, steps=100, warmup=10, check=True):
+    """SURVEY.md 8(d) configs 1-4 on this GPU in the arithmetic of the run (the headline is config 5's per-GPU share).  Configs 2 and 3
+    -- whose stream counts (32, 64) select other kernels than the headline's 256: few-streams time tiles, no chain launches -- are also
+    CHECKED against the CPU oracle at exactly their stream count (self_check on a fresh model, 3 steps)."""
+    def compact(c):
+        return {k: c[k] for k in ("ok", "model", "path", "streams", "steps", "max_abs_dz", "max_abs_dy", "indices_equal", "frames_with_flipped_indices",
+                                  "unexplained_flips", "min_reference_top2_margin")}
+
     from audiodec_amd import synth
     from audiodec_amd.audiodec import AudioDec, assign_model
     import contextlib, io
@@ -568,10 +713,14 @@ def extra_configs(root, dev, steps=100, warmup=10):
         x = audio(32, HOP)
         t = timed(lambda: ad.tx_encoder.quantize(ad.tx_encoder.encode(x)), steps, warmup)
         res["cfg2_vctk_encoder_rvq_B32"] = {"ms_per_step": round(1e3 * t, 4), "frames_per_s": round(32 / t, 1)}
+        if check:
+            res["cfg2_vctk_encoder_rvq_B32"]["self_check"] = compact(self_check(root, dev, 32, 1, True, steps=3, model="vctk_sym", decode=False))
         ad = load("vctk_sym", 64, 1)
         x = audio(64, HOP)
         t = timed(lambda: ad.decoder.decode(ad.rx_encoder.lookup(ad.tx_encoder.quantize(ad.tx_encoder.encode(x)))), steps, warmup)
         res["cfg3_vctk_sym_full_B64"] = {"ms_per_step": round(1e3 * t, 4), "frames_per_s": round(64 / t, 1)}
+        if check:
+            res["cfg3_vctk_sym_full_B64"]["self_check"] = compact(self_check(root, dev, 64, 1, True, steps=3, model="vctk_sym", decode=True))
         ad = load("vctk_v1", 256, 1)
         g = torch.Generator().manual_seed(SEED)
         idx = (torch.randint(0, 1024, (8, 256, 1), generator=g) + 1024 * torch.arange(8).view(8, 1, 1)).to(dev)
@@ -643,6 +792,8 @@ def main():
     ap.add_argument("--no-self-check", action="store_true", help="skip the parity check of the timed configuration against the CPU oracle")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip SURVEY 8(d) configs 1-4")
     ap.add_argument("--no-op-profile", action="store_true")
+    ap.add_argument("--no-t5", action="store_true", help="skip the secondary roofline of the named kernel at the reference streamer's default chunk (5 frames per call)")
+    ap.add_argument("--no-guarded", action="store_true", help="skip the guard=True leg (AudioDec's default: every program step checked on the device)")
     ap.add_argument("--dump-ops", type=str, default=None, help="write the per-op HIP-event table (CSV) here")
     args = ap.parse_args()
 
@@ -752,7 +903,9 @@ def main():
         elapsed = time.perf_counter() - t0
         if args.pmc_markers:
             torch.arange(PMC_MARKER_N, device=dev); torch.cuda.synchronize()
+    elapsed_rank = elapsed
     elapsed = shard.max_over_ranks(elapsed, coll_dev)
+    per_rank = shard.gather_floats(B * args.steps * FPS / elapsed_rank, coll_dev)      # every rank's own frames/s over ITS timed region
     frames = world * B * args.steps * FPS
     ms_per_step = 1e3 * elapsed / args.steps
     out = {
@@ -778,7 +931,14 @@ def main():
                               if args.precision == "split16" else "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) everywhere"},
         "executor": ("HIP graphs: one captured launch sequence per program and cursor phase, replayed by hipGraphLaunch (ops on caller buffers stay "
                      "ordinary launches)") if args.graph == "1" else "ordinary launches from the C++ program runner (one C call per program and step)",
+        "guard": "off for `value` (AudioDec(guard=False): three batches in flight on three HIP streams, nothing synchronises per step; device flag words "
+                 "checked once after the run and asserted 0); the guard=True default of the facade is timed as `guarded`",
         "frames_per_s_per_gpu": round(frames / elapsed / world, 1),
+        "frames_per_s_of_each_rank": [round(v, 1) for v in per_rank],
+        "distributed": {"world_size": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+                        "ranks_per_gpu": 1, "steady_state_collectives": 0,
+                        "note": "one process per GPU, streams [r*B, (r+1)*B) on rank r, full weight replica per rank; the collectives of a run are the "
+                                "checkpoint broadcast, the barrier around the timed region and the max / gather of the elapsed times"},
         "latency_ms": {},
         "realtime_streams_supported_per_gpu": int(frames / elapsed / world / 160.0),
     }
@@ -799,16 +959,18 @@ def main():
         # rank 0 prices its own GPU's kernels at every N (a few seconds); the legs below it are single-GPU extras
         with torch.no_grad():
             if not args.no_op_profile and NG == 1:
-                rows = op_profile(ad, xs, B, 10, FPS)
+                rows = op_profile(ad, xs, B, 10, FPS)                                  # serial: one HIP stream, nothing else on the chip
+                rows_pipe = op_profile(ad, xs, B, 10, FPS, pipe=pipe) if pipe is not None else None      # the schedule `value` was timed in
                 if args.dump_ops:
                     with open(args.dump_ops, "w") as f:
-                        f.write("prog,op,kernel,cin_g,cout_g,groups,taps,dil,t_out_per_stream,us,gflop,tflops\n")
-                        for r in rows:
+                        f.write("prog,op,kernel,cin_g,cout_g,groups,taps,dil,t_out_per_stream,us,gflop,tflops,us_pipelined\n")
+                        for qi, r in enumerate(rows):
                             c = r["op"].conv
                             f.write(f"{r['prog']},{r['name']},{r['kernel']},{c.cin_g},{c.cout_g},{c.groups},{c.taps},{c.dilation},"
                                     f"{r['op'].rate_out},{1e3 * r['ms']:.2f},{r['flops'] / 1e9:.3f},"
-                                    f"{(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0:.2f}\n")
-                roof, roof_ct, kernels = roofline_from(rows, B, FPS, args.precision == "split16")
+                                    f"{(r['flops'] / (r['ms'] * 1e-3) / 1e12) if r['ms'] > 0 else 0:.2f},"
+                                    f"{(1e3 * rows_pipe[qi]['ms']) if rows_pipe is not None else float('nan'):.2f}\n")
+                roof, roof_ct, kernels = roofline_from(rows, B, FPS, args.precision == "split16", rows_pipe)
                 if roof_ct is not None:
                     # the transposed conv of the named kernel BY ITSELF (conv_up16, 300 back-to-back launches): the figure of rounds 1-2, kept for
                     # comparison with the fused launch above
@@ -820,6 +982,8 @@ def main():
                 out["roofline"] = roof
                 out["roofline_convtr"] = roof_ct
                 out["kernels"] = kernels
+                if rank == 0 and world == 1 and FPS == 1 and not args.no_t5:
+                    out["roofline_convtr_T5"] = convtr_t5(tmp.name, dev, sds[dec_tag], B, args.precision == "split16")
                 enc_ms = sum(r["ms"] for r in rows if r["prog"] == "encoder")
                 dec_ms = sum(r["ms"] for r in rows if r["prog"].startswith("decoder"))
                 out["latency_ms"]["encoder_kernels_at_batch"] = round(enc_ms, 4)
@@ -843,6 +1007,47 @@ def main():
             out["latency_ms"]["encode_decode_single_stream_median"] = round(float(np.median(lat)), 4)
             out["latency_ms"]["encode_decode_single_stream_min"] = round(float(np.min(lat)), 4)
             out["latency_ms"]["note"] = "one 300-sample frame per stream per call; x on device -> y on device, host-synchronised"
+            if not args.no_guarded and NG == 1:
+                # The same workload with AudioDec's DEFAULT guard (guard=True): every program step is followed by a check of the program's
+                # device flag word -- one 1-thread kernel + a stream synchronisation per program and step -- so a split-f16 range overflow is
+                # repaired on the spot (stream_generator._step).  The pipeline object is the same, but its three HIP streams can no longer
+                # overlap batches (the host waits after every program), so this is the price a caller pays for keeping the default.
+                adg = build_audiodec(tmp.name, dev, B, FPS, guard=True)
+                pg = None if args.serial else TxRxPipeline(adg, dev)
+                rung = (lambda x: step(adg, x)) if pg is None else pg.step
+                ng = max(20, args.steps // 2)
+                if pg:
+                    pg.enter()
+                for i in range(5 + args.preroll // 2):
+                    rung(xs[i % n_buf])
+                if pg:
+                    pg.exit()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                if pg:
+                    pg.enter()
+                for i in range(ng):
+                    rung(xs[i % n_buf])
+                if pg:
+                    pg.exit()
+                torch.cuda.synchronize()
+                eg = time.perf_counter() - tg
+                ad1g = build_audiodec(tmp.name, dev, 1, 1, guard=True)
+                for _ in range(10):
+                    step(ad1g, x1)
+                torch.cuda.synchronize()
+                latg = []
+                for _ in range(50):
+                    t1 = time.perf_counter()
+                    step(ad1g, x1)
+                    torch.cuda.synchronize()
+                    latg.append(1e3 * (time.perf_counter() - t1))
+                out["guarded"] = {"value": round(B * ng * FPS / eg, 1), "unit": "frames/s", "ms_per_step": round(1e3 * eg / ng, 4), "steps": ng,
+                                  "single_stream_ms": round(float(np.median(latg)), 4), "single_stream_ms_min": round(float(np.min(latg)), 4),
+                                  "what": "guard=True, the default of AudioDec(...): the same streams / schedule object / inputs, every program step "
+                                          "checked on the device (adk_program_flags: one 1-thread kernel + one stream synchronisation per program and "
+                                          "step) and a split-f16 range overflow repaired in place on the exact-f32 kernels"}
+                del adg, ad1g
             if not args.no_other_precision and NG == 1:
                 # the same workload through the other arithmetic (same weights, same inputs, same schedule)
                 other = "f32" if args.precision == "split16" else "split16"
@@ -874,7 +1079,7 @@ def main():
             if not args.no_self_check and NG == 1:
                 out["self_check"] = self_check(tmp.name, dev, B, FPS, args.serial)
             if not args.no_extra_configs:
-                out["extra_configs"] = extra_configs(tmp.name, dev)
+                out["extra_configs"] = extra_configs(tmp.name, dev, check=not args.no_self_check)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             ncpu = os.cpu_count() or 1
@@ -901,6 +1106,9 @@ def main():
     assert flags.value == 0, f"device error flags {flags.value}: results invalid"
     if "self_check" in out:
         assert out["self_check"]["ok"], f"parity check of the timed configuration failed: {out['self_check']}"
+    for k_, v_ in out.get("extra_configs", {}).items():
+        if isinstance(v_, dict) and "self_check" in v_:
+            assert v_["self_check"]["ok"], f"parity check of {k_} failed: {v_['self_check']}"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

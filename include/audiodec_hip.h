@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 10
+#define ADK_ABI_VERSION 11
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -62,7 +62,8 @@ int adk_abi_version(void);
  * partial tile -- results of that launch are invalid; bit 2: adk_codes_pack saw an index that
  * is not a code of its stage; bit 3: a split-f16 kernel produced a non-finite output -- an operand beyond the f16 range (|v| > 65504) or a
  * non-finite input; results of that launch are invalid); the value is the OR over every device the library
- * has launched on; reading synchronises those devices and clears the words.  The Python facade turns a set bit
+ * has launched on and every program on them (one sweep kernel per device over the pool the program words live in);
+ * reading synchronises those devices and clears the words.  The Python facade turns a set bit
  * into an exception at its synchronisation points (audiodec_amd/native.py: raise_on_device_flags) */
 int adk_debug_flags(int32_t* out);
 /* tuning hook: force the MFMA conv tile config (0..6), -1 = heuristic (also env ADK_CONV_CFG) */
@@ -267,6 +268,12 @@ int adk_program_reset(adk_program* p, void* stream);
  * it exactly; audiodec_amd/stream_generator.py does that automatically for synchronous callers ("guard"). */
 int adk_program_flags(adk_program* p, void* stream, int32_t* out);
 int adk_program_rewind(adk_program* p, int32_t frames);
+/* "Fresh" = no step since create / reset: the one state bit of a program besides its arena and cursors (the offline lowering's
+ * ADK_OP_HIST_REPLICATE -- the replication pad of CausalConvTranspose1d.forward, layers/conv_layer.py:189-192 -- runs on a fresh
+ * step only).  adk_program_rewind restores the value from before the rewound step; get / set carry it over to a program that
+ * takes this one's place (the exact-f32 twin of the guard, also for offline programs). */
+int adk_program_get_fresh(const adk_program* p);
+int adk_program_set_fresh(adk_program* p, int32_t fresh);
 /* How many persistent workgroups the stream-K conv launches of this program use (multiple of 8; 0 = default = the whole
  * chip, 2 per CU).  A caller that runs several programs CONCURRENTLY on different HIP streams (software pipeline over
  * batches, bench.py) gives each a share: at 3 concurrent programs 256 measured best (210 k vs 189 k frames/s). */

@@ -43,7 +43,7 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
     old = os.environ.get("ADK_VOCODER_STAGES")
     os.environ["ADK_VOCODER_STAGES"] = "2"                     # bench.py --stages 2 (its default)
     try:
-        ad = load_audiodec(ckpt_root, bench.MODEL, seed, B, 1, split16)
+        ad = load_audiodec(ckpt_root, bench.MODEL, seed, B, 1, split16, guard=False)      # as bench.py: nothing synchronises between steps
     finally:
         if old is None:
             del os.environ["ADK_VOCODER_STAGES"]
@@ -416,4 +416,29 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
     finally:
         native.set_option("chain_max_channels", 128)
         native.set_option("chain_min_blocks", 160)
+    assert native.device_flags() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 2 and 3 at EXACTLY their stream counts (kernel choice is a function of the stream count: few-streams time
+# tiles, chains only from 160 workgroups), through the same checker bench.py's extra_configs runs beside the timing
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("split16", [True, False], ids=["split16", "f32"])
+@pytest.mark.parametrize("cfg", ["cfg2_encoder_rvq_B32", "cfg3_full_B64"])
+def test_survey_configs_2_and_3_match_oracle_at_their_stream_counts(gpu, ckpt_root, monkeypatch, cfg, split16):
+    """`symAD_vctk_48000_hop300 encoder+RVQ only, batch=32` and `... full encode->RVQ->decode, batch=64 streaming (hop 300)`
+    (BASELINE.json configs 2 / 3): 6 single-frame steps of a fresh `vctk_sym` model against the B-stream oracle -- latent and
+    waveform <= 1e-4 max-abs, indices bit-exact (a flip only where the reference's own top-2 margin is below 1e-4)."""
+    import bench
+    monkeypatch.setenv("ADK_SPLIT16", "1" if split16 else "0")
+    monkeypatch.setenv("ADK_VOCODER_STAGES", "1")
+    B, decode = (32, False) if cfg.startswith("cfg2") else (64, True)
+    res = bench.self_check(ckpt_root, DEV, B, 1, True, steps=6, model="vctk_sym", decode=decode)
+    assert res["streams"] == B and res["steps"] == 6 and res["model"] == "vctk_sym"
+    assert res["max_abs_dz"] < WAVE_TOL, res
+    assert res["unexplained_flips"] == 0, res
+    if decode:
+        assert res["max_abs_dy"] < WAVE_TOL and res["streams_compared_to_the_end"] >= B - 2, res
+    assert res["ok"], res
+    from audiodec_amd import native
     assert native.device_flags() == 0

@@ -25,7 +25,7 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, f"{name}.npz"), allow_pickle=False)
 
 
-def load_audiodec(ckpt_root, model, seed, num_streams, max_frames, split16=False):
+def load_audiodec(ckpt_root, model, seed, num_streams, max_frames, split16=False, guard=None):
     from audiodec_amd.audiodec import AudioDec
     from audiodec_amd.configs import checkpoint_paths as assign_model      # also knows the EXTRA_ALIASES test models
     synth.write_model(ckpt_root, model, seed)
@@ -35,7 +35,7 @@ def load_audiodec(ckpt_root, model, seed, num_streams, max_frames, split16=False
     os.environ["ADK_SPLIT16"] = "1" if split16 else "0"       # read by the generators when they are constructed
     try:
         sr, enc_ckpt, dec_ckpt = assign_model(model)
-        ad = AudioDec(tx_device=DEV, rx_device=DEV, num_streams=num_streams, max_frames=max_frames)
+        ad = AudioDec(tx_device=DEV, rx_device=DEV, num_streams=num_streams, max_frames=max_frames, guard=guard)
         ad.load_transmitter(enc_ckpt)
         ad.load_receiver(enc_ckpt, dec_ckpt)
     finally:
@@ -576,17 +576,19 @@ def test_wire_format_matches_oracle_bit_for_bit(gpu):
         assert np.array_equal(back, idx)
     # edge: empty batch of frames
     assert wire.pack_codes(torch.zeros(8, 1, 0, dtype=torch.int64, device=gpu)).shape == (1, 0, 10)
-    # an index that is not a code of its stage: packing is asynchronous (no exception, no synchronisation inside a tick), the
-    # failure sits in the sticky device flags until the caller's next check; check=True does that check in place
+    # an index that is not a code of its stage: by default (check=True) the call synchronises and raises -- a payload it returns is
+    # safe to ship; the real-time tick paths pass check=False: no exception, no synchronisation, the failure sits in the sticky
+    # device flags until the caller's next check (and the bad index travels as code 0, never spilling into its neighbours' bits)
     from audiodec_amd import native
     assert native.device_flags() == 0
     bad = torch.from_numpy(gold_idx).to(gpu).clone()
     bad.view(8, -1)[3, 0] = 5                                            # a stage-0 index in stage 3's row
-    wire.pack_codes(bad, 1024)
+    with pytest.raises(ValueError):
+        wire.pack_codes(bad, 1024)
+    assert native.device_flags() == 0                                    # (the raise consumed the flag)
+    wire.pack_codes(bad, 1024, check=False)
     assert native.device_flags() == native.FLAG_BAD_CODE
     assert native.device_flags() == 0                                    # read-and-clear
-    with pytest.raises(ValueError):
-        wire.pack_codes(bad, 1024, check=True)
 
 
 def test_packed_lookup_equals_lookup(gpu, ckpt_root):

@@ -258,3 +258,55 @@ def test_demofile_round_trip_cli(gpu, tmp_path):
         with torch.no_grad():
             yo = dec.decode(rx.lookup(tx.quantize(tx.encode(xt))))[0, 0, :3100].numpy()
         assert np.abs(y[:, c] - yo).max() <= WAVE_TOL + 2.0 / 32767
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("at_frame", [0, 5], ids=["first_chunk", "later_chunk"])
+@pytest.mark.parametrize("model", ["vctk_v1", "vctk_sym"])
+def test_offline_programs_are_repaired_by_the_guard_too(gpu, tmp_path, monkeypatch, model, at_frame):
+    """The file-level drivers lower the NON-streaming forward (set_offline) and run it in the split-f16 arithmetic by default.  An
+    operand beyond the f16 range must cost them nothing either: the chunk that overflowed is repeated on the exact-f32 kernels, with
+    the "first step after reset" bit restored -- the replication pad of CausalConvTranspose1d.forward (layers/conv_layer.py:189-192)
+    is applied on that step only, so the repeat of the FIRST chunk must apply it again and the repeat of a later chunk must not.
+    zq of one frame is scaled by 1e5 in the first / in a later 3-frame chunk of a 7-frame utterance; the result is compared with the
+    oracle's forward of the same zq (exact f32), and the next utterance -- on the now exact-f32 program -- with the plain forward."""
+    import warnings
+    from audiodec_amd import offline
+    monkeypatch.setenv("ADK_SPLIT16", "1")
+    seed, hop, frames = 1337, 300, 7
+    root = str(tmp_path)
+    _, enc_ckpt, dec_ckpt = synth.write_model(root, model, seed)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        tm = offline.TestMain(types.SimpleNamespace(encoder=enc_ckpt, decoder=dec_ckpt), max_frames=3)
+        tm.load_encoder()
+        tm.load_decoder()
+    finally:
+        os.chdir(cwd)
+    assert tm.decoder.split16 and tm.decoder.guard and tm.decoder.offline
+    enc, dec = _oracles(model, seed)
+    audio = _audio(seed, 0, frames * hop)
+    x = torch.tensor(audio, dtype=torch.float).transpose(1, 0).unsqueeze(1)
+    with torch.no_grad():
+        ozq = enc.analyze(x)
+        big = ozq.clone()
+        big[:, :, at_frame] *= 1e5
+        oy = dec.synthesize(big)
+        oy_plain = dec.synthesize(ozq)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = tm.decode(big.to(gpu)).cpu()
+    assert any(issubclass(i.category, RuntimeWarning) and "f16 range" in str(i.message) for i in w), [str(i.message) for i in w]
+    progs = tm.decoder._decoder_stages() if hasattr(tm.decoder, "_decoder_stages") else [tm.decoder._decoder()]
+    assert any(p.demoted for p in progs)
+    assert bool(torch.isfinite(y).all()) and y.shape == oy.shape
+    cut = at_frame * hop                                     # causal: everything before the scaled frame is the plain forward
+    if cut:
+        assert float((y[..., :cut] - oy[..., :cut]).abs().max()) <= WAVE_TOL
+    rel = float((y[..., cut:] - oy[..., cut:]).abs().max() / oy[..., cut:].abs().max().clamp(min=1.0))
+    assert rel < 1e-3, f"{model}: repaired chunk differs from the exact-f32 forward by {rel:.3e} (relative)"
+    from audiodec_amd import native
+    assert native.device_flags() == 0
+    y2 = tm.decode(ozq.to(gpu)).cpu()                        # next utterance: reset + forward on the demoted program
+    assert float((y2 - oy_plain).abs().max()) <= WAVE_TOL

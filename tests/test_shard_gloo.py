@@ -36,6 +36,7 @@ def _worker(rank, world, port, q):
         else:
             assert allc is None
         assert shard.max_over_ranks(1.0 + rank, "cpu") == 2.0
+        assert shard.gather_floats(10.0 + rank, "cpu") == [10.0, 11.0]         # every rank's own rate, on every rank (bench.py)
         q.put((rank, "ok"))
     except Exception as e:          # pragma: no cover
         q.put((rank, repr(e)))
