@@ -47,6 +47,15 @@
 #ifndef ADK_RB16_ASYNC_TOUCH
 #define ADK_RB16_ASYNC_TOUCH 1     // 0: the L2 warm-up touches as volatile loads (each one waited for), as measured in profiles/r3_rb16_timeline.md sections 1-3
 #endif
+#ifndef ADK_RB16_RING_SLOTS32
+#define ADK_RB16_RING_SLOTS32 4    // LDS weight ring of the 32-channel chains: slots of 4 KiB = one group of two 16-k steps (round 4; see rb_mfma_ring)
+#endif
+#ifndef ADK_RB16_HIST_LATE
+#define ADK_RB16_HIST_LATE 1
+#endif
+#ifndef ADK_RB16_EARLY64
+#define ADK_RB16_EARLY64 true      // 64-channel ring variant: residual fetched under the second conv's MFMAs (true) or behind them
+#endif
 #ifndef ADK_RB16_DBG
 #define ADK_RB16_DBG 0      // tuning builds only: 1 = per-workgroup wall-clock stamps (s_memrealtime, 100 MHz) at every phase boundary of wave 0;
                             // knock-outs (results are garbage): 2 = no weight loads inside the MFMA loops, 4 = no MFMAs, 8 = one B-fragment read per loop,
@@ -171,19 +180,106 @@ __device__ __forceinline__ void rb_mfma(const unsigned char* const (&x)[NTW], in
     }
 }
 
+// ---- The same loop with the weights coming through an LDS RING that the whole workgroup shares (round 4) ----
+// rb_mfma above has every wave pull the fragments of its m-tile from L2 into registers: at 32 channels the four waves of a workgroup
+// load the SAME 2 KiB per step, at 64 channels two waves each -- 45 / 90 KB per conv and wave for two or three n-tiles of work, ~13.5 TB/s
+// of L2 reads chip-wide, which is what keeps these loops at ~60 % of their matrix-core bound (profiles/r3_rb16_timeline.md, knock-outs).
+// Here a fragment crosses the L2 -> CU path ONCE per workgroup: the weights of a conv are walked in GROUPS of 4 KiB (32 channels: two 16-k
+// steps of the one m-tile; 64 channels: one step of both m-tiles), every wave copies one 1 KiB piece of a group global -> LDS by LDS-DMA
+// (no registers, no VALU), WR slots of 4 KiB form a ring, and all waves read their A fragments from the slot (ds_read_b128, lane-linear:
+// conflict-free).  Hand-over per group, counted by hand because the compiler does not see the DMA:
+//     s_waitcnt vmcnt(n)   this wave's piece of group i has landed (n = its pieces of the groups behind i still in flight;
+//                          loads return in order, and whatever else the compiler has in flight only makes the wait stricter)
+//     s_barrier            ... and so has every other wave's; and every wave is done READING group i - 1
+//     DMA group i + WR - 1 into the slot group i - 1 just left (all waves are past their reads of it: they consumed them in MFMAs
+//                          issued before they arrived at this barrier)
+//     ds_read A (slot i), ds_read B (rows), MFMAs of the group's steps -- the k order and the accumulator order of rb_mfma: bit-identical
+// Groups are numbered through the whole launch (slot = group number mod WR, `sl` carries it from conv to conv), so the first WR - 1
+// groups of the NEXT conv can be requested as soon as a wave leaves the loop: they land under the epilogue.
+struct RbRing {
+    const unsigned char* base;      // slot 0 (generic pointer, for the ds_reads)
+    unsigned lds_addr;              // ... its LDS byte address (for M0)
+    int sl;                         // slot of the next group to be consumed (0 .. WR-1)
+};
+
+#define RB_DMA16(gptr, m0val) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                                                            : "=&s"(m0_keep_) : "v"(gptr), "s"(m0val) : "memory"); } while (0)      /* M0 is the compiler's: put back */
+
+// groups [0, min(WR - 1, NG)) of a conv: requested ahead of its loop (gsrc: this lane's source of ITS piece of group 0)
+template <int C, int TAPS, int WR>
+__device__ __forceinline__ void rb_ring_preload(const RbRing& rg, const unsigned char* gsrc, int wave) {
+    constexpr int MT = C / 32, GS = 2 / MT, NG = TAPS * (C / 16) / GS, PD = WR - 1;
+    int sl = rg.sl;
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+        if (j < NG) RB_DMA16(gsrc + (size_t)j * GS * 2048u, rg.lds_addr + (unsigned)sl * 4096u + (unsigned)wave * 1024u);
+        sl = sl + 1 == WR ? 0 : sl + 1;
+    }
+}
+
+template <int C, int TAPS, int NA, int NTW, int WR>
+__device__ __forceinline__ void rb_mfma_ring(const unsigned char* const (&x)[NTW], int dil_rs, RbRing& rg, const unsigned char* gsrc, int wave, int mt,
+                                             unsigned lane16, f32x16 (&m)[NTW], f32x16 (&c)[NTW]) {
+    constexpr int CH = C / 16, STEPS = TAPS * CH, MT = C / 32, GS = 2 / MT, NG = STEPS / GS, PD = WR - 1;
+    static_assert(MT == 1 || MT == 2, "the weight ring is built for 32 / 64 channels per group");
+    static_assert(STEPS % GS == 0 && WR >= 2 && WR <= 5, "whole groups; 2..5 ring slots");
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int behind = (NG - 1 - i) < (PD - 1) ? (NG - 1 - i) : (PD - 1);       // this wave's pieces of later groups that may stay in flight
+        // (lgkmcnt(0): this wave's LDS reads of group i - 1 have RETURNED, not merely been issued, when it arrives -- the compiler
+        // sinks MFMAs of the previous group below this statement, and with them the wait for their operands; a slot must not be
+        // handed to the DMA while a read of it is still queued)
+        if (behind <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (i + PD < NG) {
+            const int dst = rg.sl + PD >= WR ? rg.sl + PD - WR : rg.sl + PD;
+            RB_DMA16(gsrc + (size_t)(i + PD) * GS * 2048u, rg.lds_addr + (unsigned)dst * 4096u + (unsigned)wave * 1024u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* slot = rg.base + rg.sl * 4096 + lane16;
+#pragma unroll
+        for (int sg = 0; sg < GS; ++sg) {
+            const int s = i * GS + sg;
+            const int tap = s / CH, ch = s - tap * CH;
+            const int off = tap * dil_rs + 32 * ch;
+            const f16x8 Ah = *reinterpret_cast<const f16x8*>(slot + (sg * MT + mt) * 2048);
+            const f16x8 Al = *reinterpret_cast<const f16x8*>(slot + (sg * MT + mt) * 2048 + 1024);
+            f16x8 bh[NA], bl[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(x[j] + off);
+                bl[j] = *reinterpret_cast<const f16x8*>(x[j] + off + 2 * C);
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) m[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bh[j], m[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bl[j], c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) c[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh[j], c[j], 0, 0, 0);
+        }
+        rg.sl = rg.sl + 1 == WR ? 0 : rg.sl + 1;
+    }
+}
+
 // 4 waves per workgroup: wave w works on m-tile w / WM (WM = 4 / m-tiles waves share an m-tile) and on up to NTW consecutive 32-column
 // tiles of it.  SMAX = most streams a workgroup takes (sizes the register staging of the history rows).
 // WPS = waves per SIMD the register budget is cut for (2: 256 registers, 3: 168); PF = weight prefetch distance in 16-k steps;
 // EARLY_RES: the residual is fetched before the second conv's MFMA loop (16 registers per n-tile live through it);
-// LS: lockstep interval (rb_mfma).
-template <int C, int ACT, int TA, int TB, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+// LS: lockstep interval (rb_mfma); WR: slots of the shared LDS weight ring (rb_mfma_ring), 0 = every wave streams its weights into registers.
+template <int C, int ACT, int TA, int TB, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS, int WR>
 __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr int RS = 4 * C + 16;                     // LDS row stride in bytes: [C halfs hi][C halfs lo][16 B pad]
     constexpr int C8 = C / 8;
     constexpr int MT = C / 32;
     constexpr int NW = 4, NT = 64 * NW;
     constexpr int WM = NW / MT;                         // waves that share an m-tile (and its weight stream)
-    constexpr bool BIAS_LDS = C < 128 && !(C == 64 && SMAX == 2);    // bias of every conv staged in LDS -- unless the LDS is needed to the last KB for a second workgroup per CU
+    constexpr bool BIAS_LDS = C < 128 && !(C == 64 && (SMAX == 2 || WR > 0));    // bias of every conv staged in LDS -- unless the LDS is needed to the last KB for a second / third workgroup per CU
+    constexpr int RING_BYTES = WR * 4096;
+    constexpr bool BIAS_LATE = WR > 0 && !BIAS_LDS;
+    constexpr bool HIST_LATE = WR > 0 && WPS == 3 && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
+                                                     // finish / ring-store pass instead of in front of it (16 registers less at the epilogue's peak)   // bias fetched BEHIND the MFMA loop (16 registers per lane would otherwise live through it)
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
 
@@ -222,18 +318,35 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
 
     // ---- first weight fragments of conv 0: issued before anything else (their L2 round trip overlaps the staging) ----
     u32x4s ah[PF + 1], al[PF + 1];
-    auto preload = [&](const RbConv& cv, int steps) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
-        const unsigned wb = (unsigned)((g * MT + mt) * cv.ksteps) * 2048u;
+    typedef unsigned char __attribute__((address_space(3)))* lds_u8_t;
+    // the weight ring (WR > 0) sits behind the rows and the bias block; this wave's DMA piece of every group: half (hi / lo) = wave & 1,
+    // (step in group, m-tile) = wave >> 1 -- 32 channels: step; 64 channels: m-tile
+    const unsigned ring_off = (unsigned)r.spw * (unsigned)r.rps * (unsigned)RS + (BIAS_LDS ? (unsigned)r.n_convs * C * 4u : 0u);
+    RbRing rg;
+    rg.base = xs + ring_off; rg.lds_addr = (unsigned)(size_t)(lds_u8_t)xs + ring_off; rg.sl = 0;
+    auto ring_src = [&](const RbConv& cv) __attribute__((always_inline)) -> const unsigned char* {
+        const int q = wave >> 1;
+        const int mt_ = MT == 1 ? 0 : q, sg_ = MT == 1 ? q : 0;
+        return reinterpret_cast<const unsigned char*>(cv.wfrag) + ((size_t)((g * MT + mt_) * cv.ksteps + sg_)) * 2048u + (size_t)(wave & 1) * 1024u + lane16;
+    };
+    auto preload = [&](auto taps_c, const RbConv& cv) __attribute__((always_inline)) {
+        constexpr int TAPS = decltype(taps_c)::value;
+        if constexpr (WR > 0) {
+            rb_ring_preload<C, TAPS, WR>(rg, ring_src(cv), wave);
+        } else {
+            constexpr int steps = TAPS * (C / 16);
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
+            const unsigned wb = (unsigned)((g * MT + mt) * cv.ksteps) * 2048u;
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            if (s < steps) {
-                ah[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_, lane16, wb + (unsigned)s * 2048u, 0);
-                al[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_, lane16 + 1024u, wb + (unsigned)s * 2048u, 0);
+            for (int s = 0; s < PF; ++s) {
+                if (s < steps) {
+                    ah[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_, lane16, wb + (unsigned)s * 2048u, 0);
+                    al[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_, lane16 + 1024u, wb + (unsigned)s * 2048u, 0);
+                }
             }
         }
     };
-    preload(r.conv[0], TA * (C / 16));
+    if constexpr (WR == 0) preload(std::integral_constant<int, TA>(), r.conv[0]);
 
     // ---- L2 warm-up.  Every workgroup of the launch walks the same weights at about the same time, and between two calls
     // (a whole pipeline step, ~100 MB of other traffic) they have left the 4 MiB L2 of the XCD: each 2 KiB fragment pair would be
@@ -247,9 +360,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     // Nothing ever waits for a touch by name; the compiler's own s_waitcnt vmcnt(n) assume fewer loads in flight than there are
     // (loads return in order: they wait for more, never for less), and the last touches of a launch go out before the last conv's
     // MFMA loop, whose weight waits retire them long before the workgroup's LDS is released.
-    typedef unsigned char __attribute__((address_space(3)))* lds_u8_t;
-    const unsigned touch_m0 = (unsigned)(size_t)(lds_u8_t)xs + (unsigned)r.spw * (unsigned)r.rps * (unsigned)RS +
-                              (BIAS_LDS ? (unsigned)r.n_convs * C * 4u : 0u);          // the last kRbTouchSink bytes of the dynamic LDS
+    const unsigned touch_m0 = rg.lds_addr + (unsigned)RING_BYTES;                      // the last kRbTouchSink bytes of the dynamic LDS
 #if ADK_RB16_ASYNC_TOUCH
 #define RB_TOUCH(ptr) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" \
                                                         : "=&s"(m0_keep_) : "v"(ptr), "s"(touch_m0) : "memory"); } while (0)      /* M0 is the compiler's: put back */
@@ -268,6 +379,12 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
         }
     };
     if (r.warm) warm_weights(r.conv[0]);
+    if constexpr (WR > 0) {
+        // ring: the touches go out BEFORE the DMA requests they are meant to speed up -- a counted wait for a DMA piece also waits for
+        // every older touch (loads return in order), so a touch may never sit between a piece and its wait: the weights of conv k + 2
+        // are touched when conv k's loop is left, in front of the requests for conv k + 1's first groups (here: conv 1, then conv 0)
+        if (r.warm) warm_weights(r.conv[1]);
+    }
     for (int k = 1; k < (r.warm ? r.n_convs : 0); ++k) { // history rows [-hist_k, 0) of node k, all streams of this workgroup: 16 bytes of every 128
         const RbNode& nd = r.node[k];
         const int hk = r.conv[k].hist;
@@ -281,6 +398,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
             RB_TOUCH(nd.base + ((size_t)(b0 + s) * nd.rows + row) * nd.ch + nd.choff + g * nd.gstride + 32 * li);
         }
     }
+    if constexpr (WR > 0) preload(std::integral_constant<int, TA>(), r.conv[0]);      // ring groups 0 .. WR-2 of conv 0: they land under the staging below
 
     // ---- stage the chain input: rows [-hist_0, T) of every stream, activated and split ----
     {
@@ -425,13 +543,19 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     // the MFMA loop of one conv over this wave's n-tiles (a wave with one tile less than NTW runs the shorter loop)
     auto conv_loop = [&](auto taps_c, const RbConv& cv, f32x16 (&m)[NTW], f32x16 (&c)[NTW]) __attribute__((always_inline)) {
         constexpr int TAPS = decltype(taps_c)::value;
-        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
-        const unsigned wbase = (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u;
         const unsigned char* x[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) x[j] = xs + (lrow[j] - cv.hist) * RS + 16 * lh;
-        if (NTW > 2 && ntw < NTW) rb_mfma<C, TAPS, PF, LS, (NTW > 2 ? NTW - 1 : NTW), NTW>(x, cv.dil * RS, rsrc_w, lane16, wbase, ah, al, m, c);
-        else rb_mfma<C, TAPS, PF, LS, NTW, NTW>(x, cv.dil * RS, rsrc_w, lane16, wbase, ah, al, m, c);
+        if constexpr (WR > 0) {
+            const unsigned char* gsrc = ring_src(cv);
+            if (NTW > 2 && ntw < NTW) rb_mfma_ring<C, TAPS, (NTW > 2 ? NTW - 1 : NTW), NTW, WR>(x, cv.dil * RS, rg, gsrc, wave, mt, lane16, m, c);
+            else rb_mfma_ring<C, TAPS, NTW, NTW, WR>(x, cv.dil * RS, rg, gsrc, wave, mt, lane16, m, c);
+        } else {
+            const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cv.wfrag), 0, cv.w_bytes, 0x00020000);
+            const unsigned wbase = (unsigned)((g * MT + mt) * cv.ksteps + ((ADK_RB16_DBG & 16) ? (blockIdx.x * 5) % 24 : 0)) * 2048u;
+            if (NTW > 2 && ntw < NTW) rb_mfma<C, TAPS, PF, LS, (NTW > 2 ? NTW - 1 : NTW), NTW>(x, cv.dil * RS, rsrc_w, lane16, wbase, ah, al, m, c);
+            else rb_mfma<C, TAPS, PF, LS, NTW, NTW>(x, cv.dil * RS, rsrc_w, lane16, wbase, ah, al, m, c);
+        }
     };
 
     const int units = r.n_convs >> 1;
@@ -447,16 +571,19 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { m[j][e] = 0.f; c[j][e] = 0.f; }
             float4 breg[4];
-            bias_issue(k, breg);
-            if (r.warm) warm_weights(r.conv[k + 1]);
+            if constexpr (!BIAS_LATE) bias_issue(k, breg);
+            if (WR == 0 && r.warm) warm_weights(r.conv[k + 1]);
             conv_loop(std::integral_constant<int, TA>(), cv, m, c);
             RB_STAMP(2 + 4 * k);
-            preload(r.conv[k + 1], TB * (C / 16));              // the next conv's first fragments arrive under the epilogue
+            if constexpr (BIAS_LATE) bias_issue(k, breg);
+            if (WR > 0 && r.warm && k + 2 < r.n_convs) warm_weights(r.conv[k + 2]);
+            preload(std::integral_constant<int, TB>(), r.conv[k + 1]);      // the next conv's first fragments / ring groups arrive under the epilogue
             float4 hu[NHP], hv[NHP];                            // history rows of the next conv's input, in flight during the epilogue
-            hist_issue(k + 1, hu, hv);
+            if constexpr (!HIST_LATE) hist_issue(k + 1, hu, hv);
             float h[NTW][16];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) { finish(k, valid[j], m[j], c[j], breg, h[j]); ring_store(k + 1, j, h[j], false); }
+            if constexpr (HIST_LATE) { __builtin_amdgcn_sched_barrier(0); hist_issue(k + 1, hu, hv); }
             RB_STAMP(3 + 4 * k);
             __syncthreads();                            // every wave is done reading the rows of conv A's input
             RB_STAMP(4 + 4 * k);
@@ -478,8 +605,8 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { m[j][e] = 0.f; c[j][e] = 0.f; }
             float4 breg[4];
-            bias_issue(k, breg);
-            if (!last && r.warm) warm_weights(r.conv[kn]);
+            if constexpr (!BIAS_LATE) bias_issue(k, breg);
+            if (WR == 0 && !last && r.warm) warm_weights(r.conv[kn]);
             // the residual (this unit's input at this lane's columns) is fetched under the MFMAs of the unit's second conv where the
             // register budget allows, else right after them
             float4 rr[NTW][4];
@@ -489,9 +616,17 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
             }
             conv_loop(std::integral_constant<int, TB>(), cv, m, c);
             RB_STAMP(2 + 4 * k);
-            preload(r.conv[kn], TA * (C / 16));
+            if constexpr (BIAS_LATE) bias_issue(k, breg);
+            if constexpr (WR > 0) {
+                if (!last) {                                    // (no registers involved: a branch costs nothing here)
+                    if (r.warm && k + 2 < r.n_convs) warm_weights(r.conv[k + 2]);
+                    preload(std::integral_constant<int, TA>(), r.conv[kn]);
+                }
+            } else {
+                preload(std::integral_constant<int, TA>(), r.conv[kn]);
+            }
             float4 hu[NHP], hv[NHP];
-            hist_issue(kn, hu, hv);
+            if constexpr (!HIST_LATE) hist_issue(kn, hu, hv);
             if constexpr (!EARLY_RES) {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) res_load(k - 1, j, rr[j]);
@@ -504,6 +639,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
                 for (int qd = 0; qd < 4; ++qd) { h[j][4 * qd] += rr[j][qd].x; h[j][4 * qd + 1] += rr[j][qd].y; h[j][4 * qd + 2] += rr[j][qd].z; h[j][4 * qd + 3] += rr[j][qd].w; }
                 ring_store(k + 1, j, h[j], true);
             }
+            if constexpr (HIST_LATE) { __builtin_amdgcn_sched_barrier(0); hist_issue(kn, hu, hv); }
             RB_STAMP(3 + 4 * k);
             if (!last) {
                 __syncthreads();
@@ -519,7 +655,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     if (bad) atomicOr(r.err, 8);
 }
 
-struct RbPlan { int C, ta, tb, ntw, spw, n_tiles, hm, rps; size_t lds; long long blocks; };
+struct RbPlan { int C, ta, tb, ntw, spw, n_tiles, hm, rps, wr; size_t lds; long long blocks; };
 
 int rb_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
@@ -533,6 +669,18 @@ int rb_streams_per_wg(int C, int batch, int t) {
     const int max_ntw = C == 128 ? 2 : 4;                         // n-tiles per wave the instantiations go up to
     while (s > 1 && (s > batch || (s * t + 31) / 32 > max_ntw * wm)) --s;
     return s;
+}
+
+// Slots of the shared LDS weight ring for this geometry (0: the waves stream their weights into registers, as in round 3).
+// 32 channels: the 4 waves of a workgroup share ONE m-tile -- a fragment crosses L2 -> CU once instead of four times; 64 channels: two
+// waves per m-tile -- once instead of twice.  128 channels: every wave has an m-tile of its own, nothing to share.
+// ADK_RB16_RING=0 switches it off (A/B); the variants below are the ones instantiated.
+int rb_ring_slots(int C, int ntw, int spw) {
+    static const int on = rb_knob("ADK_RB16_RING", 1);
+    if (!on) return 0;
+    if (C == 32 && (ntw == 2 || ntw == 3)) return ntw == 3 ? ADK_RB16_RING_SLOTS32 : 3;
+    if (C == 64 && ntw == 2 && spw == 1) return 3;        // three 4 KiB slots is what three workgroups per CU leave room for
+    return 0;
 }
 
 // Geometry of the launch, or false when the chain does not fit this kernel for this call.
@@ -549,8 +697,9 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
     if (pl.hm > kRbMaxHist) return false;
     pl.rps = pl.hm + T;
-    const bool bias_lds = pl.C < 128 && !(pl.C == 64 && (pl.spw > 1 || pl.ntw > 2));        // (as BIAS_LDS of the instantiation rb_by_taps picks)
-    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0) + kRbTouchSink;
+    pl.wr = rb_ring_slots(pl.C, pl.ntw, pl.spw);
+    const bool bias_lds = pl.C < 128 && !(pl.C == 64 && (pl.spw > 1 || pl.ntw > 2 || pl.wr > 0));        // (as BIAS_LDS of the instantiation rb_by_taps picks)
+    pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0) + (size_t)pl.wr * 4096 + kRbTouchSink;
     if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 2 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
     pl.blocks = (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups;
     return pl.blocks <= 0x7fffffffLL;
@@ -600,9 +749,9 @@ bool conv_rb16_fusable(const ConvArgs* c, int n) {
 }
 
 namespace {
-template <int C, int ACT, int TA, int TB, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+template <int C, int ACT, int TA, int TB, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS, int WR>
 int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
-    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NTW, SMAX, WPS, PF, EARLY_RES, LS>;
+    auto kern = conv_rb16_kernel<C, ACT, TA, TB, NTW, SMAX, WPS, PF, EARLY_RES, LS, WR>;
     if (pl.lds > 64 * 1024) {
         static bool attr_set_dev[kMaxDevices] = {};     // function attributes are per device
         bool& attr_set = attr_set_dev[current_device()];
@@ -616,12 +765,12 @@ int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
     return ADK_OK;
 }
 
-template <int C, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS>
+template <int C, int NTW, int SMAX, int WPS, int PF, bool EARLY_RES, int LS, int WR = 0>
 int rb_by_taps(const RbArgs& r, const RbPlan& pl, int act, hipStream_t s) {
-    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
-    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
-    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
-    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NTW, SMAX, WPS, PF, EARLY_RES, LS>(r, pl, s);
+    if (act == ADK_ACT_ELU) return rb_go<C, ADK_ACT_ELU, 7, 1, NTW, SMAX, WPS, PF, EARLY_RES, LS, WR>(r, pl, s);
+    if (pl.ta == 11) return rb_go<C, ADK_ACT_LEAKY, 11, 11, NTW, SMAX, WPS, PF, EARLY_RES, LS, WR>(r, pl, s);
+    if (pl.ta == 7) return rb_go<C, ADK_ACT_LEAKY, 7, 7, NTW, SMAX, WPS, PF, EARLY_RES, LS, WR>(r, pl, s);
+    return rb_go<C, ADK_ACT_LEAKY, 3, 3, NTW, SMAX, WPS, PF, EARLY_RES, LS, WR>(r, pl, s);
 }
 }  // namespace
 
@@ -665,6 +814,14 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     // (32 channels used to run as 5 waves x 2 tiles: the hardware starts every workgroup's waves on the same SIMD, so one SIMD
     // carried two waves of every co-resident workgroup and a second 5-wave workgroup did not even fit at 168 registers --
     // profiles/r3_rb16_timeline.md.  Now 4 waves x (3, 3, 2, 2) tiles, the odd tiles rotating with the workgroup.)
+    // Round 4: with the shared LDS weight ring (pl.wr slots, rb_mfma_ring) no weight fragment lives in registers -- the PF argument is
+    // then unused (1) -- and the 168-register variants have room for the residual again.
+    if (pl.C == 32 && pl.wr > 0) {
+        if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, 1, true, 0, 3>(r, pl, act, s);
+        if (pl.ta == 11) return rb_by_taps<32, 3, 1, 2, 1, false, 0, ADK_RB16_RING_SLOTS32>(r, pl, act, s);
+        return rb_by_taps<32, 3, 1, 2, 1, true, 0, ADK_RB16_RING_SLOTS32>(r, pl, act, s);
+    }
+    if (pl.C == 64 && pl.wr > 0) return rb_by_taps<64, 2, 1, 3, 1, ADK_RB16_EARLY64, 0, 3>(r, pl, act, s);
     if (pl.C == 32) {
         if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, ADK_RB16_PF32, true, 0>(r, pl, act, s);
         // (three tiles, K11 blocks of the vocoder: with the residual fetched AFTER the second conv's loop the kernel has 1 spilled register

@@ -338,8 +338,8 @@ def _frac(flops, ms, peak):
 def roofline_from(rows_serial, streams, fps=1, split16=False, rows_pipe=None):
     """The roofline objects of the JSON line.  rows_serial: per-op events of the serial schedule; rows_pipe: of the pipelined schedule
     (None for --serial runs).  The dominant kernel is picked by its share of the event time in the schedule `value` is timed in; `frac`
-    is priced on THAT schedule's live events (raw: every launch's time includes one event record), with the serial figure, the
-    minus-one-event-record estimates and the dispatch durations of the committed rocprofv3 kernel traces of both schedules beside it."""
+    prices it on its dispatch duration in THAT schedule (committed rocprofv3 kernel trace of this build; live events when there is none),
+    with the other schedule, the live event figures and the minus-one-event-record estimate beside it."""
     launches_s, by_s, ev_s = kernel_table(rows_serial, streams, fps)
     if rows_pipe is not None:
         launches_p, by_p, ev_p = kernel_table(rows_pipe, streams, fps)
@@ -350,20 +350,32 @@ def roofline_from(rows_serial, streams, fps=1, split16=False, rows_pipe=None):
     # algorithmic (f32-equivalent) flops against the matrix-core peak of the instruction the kernel issues: the exact-f32
     # MFMA, or -- for the split-f16 kernels -- the dense f16 MFMA peak divided by the 3 instructions per product sum
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if (split16 and "16" in dom.split("<")[0]) else FP32_MFMA_PEAK_TFLOPS
-    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     traffic, stale = pmc_traffic(dom)
     rp_us, rp_stale = rocprof_duration(dom, STEADY_STATS_FILE)
     rs_us, rs_stale = rocprof_duration(dom, SERIAL_STATS_FILE)
     fpl = d["flops"] / d["launches"]
     sched = "pipelined" if rows_pipe is not None else "serial"
+    # `frac`: the dominant kernel's algorithmic flops over its DISPATCH duration (start to end of execution) in the schedule `value` is
+    # timed in.  A HIP event pair on a stream that shares the chip with two other streams also times the wait for free compute units in
+    # front of the kernel (conv_sk16: 54 us between its events, 37 us of dispatch), so the dispatch duration comes from the rocprofv3 kernel
+    # trace of the same command committed under profiles/ -- when that trace is of THIS build (source digest); otherwise, and always beside
+    # it, the live event figures.
+    rp_fresh = rp_us is not None and rp_stale is False and sched == "pipelined"
+    rs_fresh = rs_us is not None and rs_stale is False and sched == "serial"
+    if rp_fresh or rs_fresh:
+        us = rp_us if rp_fresh else rs_us
+        achieved = fpl / (us * 1e-6) / 1e12
+        src = f"rocprofv3 kernel trace of the timed steps, {sched} schedule (profiles/{STEADY_STATS_FILE if rp_fresh else SERIAL_STATS_FILE}, same source digest as this build)"
+    else:
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        src = f"live HIP events, {sched} schedule (no committed rocprofv3 trace of this build: the kernels were rebuilt since profiles/{STEADY_STATS_FILE})"
     roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "frac_schedule": sched,
-            "frac_pipelined": _frac(d["flops"], d["ms"], peak) if rows_pipe is not None else None,
-            "frac_serial": _frac(ds["flops"], ds["ms"], peak),
-            "frac_pipelined_minus_event_estimate": _frac(d["flops"], d["ms_est"], peak) if rows_pipe is not None else None,
-            "frac_serial_minus_event_estimate": _frac(ds["flops"], ds["ms_est"], peak),
-            "frac_rocprof_pipelined": _frac(fpl, rp_us * 1e-3, peak) if rp_us else None,
-            "frac_rocprof_serial": _frac(fpl, rs_us * 1e-3, peak) if rs_us else None,
+            "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "frac_schedule": sched, "frac_source": src,
+            "frac_events_pipelined": _frac(d["flops"], d["ms"], peak) if rows_pipe is not None else None,
+            "frac_events_serial": _frac(ds["flops"], ds["ms"], peak),
+            "frac_events_serial_minus_event_estimate": _frac(ds["flops"], ds["ms_est"], peak),
+            "frac_pipelined": _frac(fpl, rp_us * 1e-3, peak) if rp_us else None,
+            "frac_serial": _frac(fpl, rs_us * 1e-3, peak) if rs_us else None,
             "traffic": traffic, "traffic_stale": stale,
             "algorithmic_bytes_per_launch": mean_launch_bytes(launches_p, dom),
             "traffic_note": "both are means per launch over all launches of this kernel in the timed steps: traffic = FETCH_SIZE x2 + "
@@ -371,18 +383,21 @@ def roofline_from(rows_serial, streams, fps=1, split16=False, rows_pipe=None):
                             f"{PMC_TRAFFIC_SCRIPT}, steady-state launches picked out by --pmc-markers; PMC counters cannot be read from inside the "
                             "bench process), not collected live -- traffic_stale says whether the kernels were rebuilt from other sources since; "
                             "algorithmic = input rows incl. history + weights + outputs (+ residual / state rows), once each",
-            "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 2),
-            "avg_launch_us_serial": round(1e3 * ds["ms"] / ds["launches"], 2),
+            "launches_per_step": d["launches"],
+            "avg_launch_us": rp_us if rp_fresh else (rs_us if rs_fresh else round(1e3 * d["ms"] / d["launches"], 2)),
+            "avg_launch_us_pipelined": rp_us, "avg_launch_us_serial": rs_us,
+            "avg_launch_us_events_pipelined": round(1e3 * d["ms"] / d["launches"], 2) if rows_pipe is not None else None,
+            "avg_launch_us_events_serial": round(1e3 * ds["ms"] / ds["launches"], 2),
             "event_record_us": round(1e3 * ev_p, 2), "event_record_us_serial": round(1e3 * ev_s, 2),
-            "avg_launch_us_rocprof_pipelined": rp_us, "avg_launch_us_rocprof_serial": rs_us,
             "rocprof_stale": None if rp_stale is None and rs_stale is None else bool(rp_stale or rs_stale),
-            "duration_note": "avg_launch_us / frac: live HIP events on the launch stream in the PIPELINED schedule (three HIP streams, batches in flight in "
-                             "front of and behind the profiled one -- the schedule `value` is timed in); every figure includes ONE event record per launch "
-                             "(event_record_us, measured in the run on the ops that ran inside another op's launch).  *_serial: the same on one HIP stream with "
-                             "nothing else on the chip.  *_minus_event_estimate: ONE measured event record subtracted per launch -- an estimate.  "
-                             f"*_rocprof_*: flops_per_launch over the dispatch duration of this kernel in the committed rocprofv3 kernel traces of the timed "
-                             f"steps (profiles/{STEADY_STATS_FILE} pipelined, profiles/{SERIAL_STATS_FILE} serial; tools/profile_round.sh) -- reproducible from "
-                             "those files alone; rocprof_stale says whether the kernels were rebuilt since",
+            "duration_note": "frac / frac_pipelined / frac_serial = flops_per_launch / avg_launch_us_{pipelined, serial} / peak: the launch-weighted mean "
+                             f"dispatch duration of this kernel over the timed steps in the committed rocprofv3 kernel traces (profiles/{STEADY_STATS_FILE}: "
+                             f"the three-stream schedule `value` is timed in; profiles/{SERIAL_STATS_FILE}: --serial; tools/profile_round.sh, "
+                             "tools/trace_summary.py) -- reproducible from those files alone; rocprof_stale = the kernels were rebuilt since.  *_events_*: live HIP "
+                             "events of THIS run on the launch stream (the C++ runner records one behind every op; every figure includes ONE event record, "
+                             "event_record_us, measured on the ops that ran inside another op's launch): serial they agree with the dispatch durations to "
+                             "the cost of the event; pipelined they also contain the wait for compute units the other two streams hold.  "
+                             "*_minus_event_estimate: one measured event record subtracted per launch -- an estimate",
             "flops_per_launch": fpl, "share_of_step_kernel_time": round(d["ms"] / sum(v["ms"] for v in by_p.values()), 3),
             "launches_per_step_all_kernels": len(launches_p)}
     # the north-star's named kernel: fused LeakyReLU -> ConvTranspose1d(64->32, s3) + bias (last upsampler) -- since round 3 the launch
@@ -418,23 +433,30 @@ def convtr_roofline(launches_s, launches_p, ev_s, ev_p, streams, fps):
     if launches_p is not None:
         lp = [q for q in launches_p if any(o["name"] == "upsamples.3" for o in q["ops"])]
         ms_p = lp[0]["ms"] if lp else None
-    ms_main = ms_p if ms_p is not None else ms_s
+    sched = "pipelined" if ms_p is not None else "serial"
     rp_us, rp_stale = rocprof_duration(L["kernel"], STEADY_STATS_FILE)
     rs_us, rs_stale = rocprof_duration(L["kernel"], SERIAL_STATS_FILE)
+    rp_fresh = rp_us is not None and rp_stale is False and sched == "pipelined"
+    rs_fresh = rs_us is not None and rs_stale is False and sched == "serial"
+    ms_ev = ms_p if ms_p is not None else ms_s
+    ms_main = 1e-3 * rp_us if rp_fresh else (1e-3 * rs_us if rs_fresh else ms_ev)      # as roofline.frac: dispatch duration of the timed schedule when a trace of this build is committed
     return {"kernel": what, "bound": "hbm", "achieved": gbs(ms_main), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr(ms_main),
-            "frac_schedule": "pipelined" if ms_p is not None else "serial",
-            "frac_pipelined": fr(ms_p), "frac_serial": fr(ms_s),
-            "frac_serial_minus_event_estimate": fr(max(ms_s - ev_s, 0.5 * ms_s)),
-            "frac_rocprof_pipelined": fr(rp_us * 1e-3) if rp_us else None, "frac_rocprof_serial": fr(rs_us * 1e-3) if rs_us else None,
-            "traffic": pmc_traffic(L["kernel"])[0], "avg_launch_us": round(1e3 * ms_main, 2), "avg_launch_us_serial": round(1e3 * ms_s, 2),
+            "frac_schedule": sched,
+            "frac_source": ("rocprofv3 kernel trace of the timed steps (profiles/, same source digest as this build)" if (rp_fresh or rs_fresh)
+                            else "live HIP events (no committed rocprofv3 trace of this build)"),
+            "frac_pipelined": fr(rp_us * 1e-3) if rp_us else None, "frac_serial": fr(rs_us * 1e-3) if rs_us else None,
+            "frac_events_pipelined": fr(ms_p), "frac_events_serial": fr(ms_s),
+            "frac_events_serial_minus_event_estimate": fr(max(ms_s - ev_s, 0.5 * ms_s)) if 0.0 < ev_s < 0.015 else None,
+            "traffic": pmc_traffic(L["kernel"])[0], "avg_launch_us": round(1e3 * ms_main, 2),
+            "avg_launch_us_pipelined": rp_us, "avg_launch_us_serial": rs_us,
+            "avg_launch_us_events_pipelined": round(1e3 * ms_p, 2) if ms_p is not None else None, "avg_launch_us_events_serial": round(1e3 * ms_s, 2),
             "event_record_us_serial": round(1e3 * ev_s, 2),
-            "avg_launch_us_rocprof_pipelined": rp_us, "avg_launch_us_rocprof_serial": rs_us,
             "rocprof_stale": None if rp_stale is None and rs_stale is None else bool(rp_stale or rs_stale),
             "bytes_per_launch": bytes_alg, "fused_with_conv_out": fused,
             "fp32_tflops": round(L["flops"] / (ms_main * 1e-3) / 1e12, 2),
-            "how": "live HIP events around the launch (each figure includes one event record): frac / avg_launch_us in the pipelined three-stream "
-                   "schedule, *_serial on one HIP stream with nothing else on the chip; *_minus_event_estimate subtracts one measured event record; "
-                   "*_rocprof_* = bytes_per_launch over the dispatch duration in the committed rocprofv3 kernel traces of the same schedules"}
+            "how": "frac / frac_pipelined / frac_serial: bytes_per_launch over the launch's dispatch duration in the committed rocprofv3 kernel traces of the "
+                   "timed steps (three-stream schedule / --serial); *_events_*: live HIP events around the launch in this run (each includes one event "
+                   "record; pipelined also the wait for compute units held by the other streams); *_minus_event_estimate subtracts one measured event record"}
 
 
 def convtr_standalone(dev, sd_dec, B, fps, split16, iters=300):
@@ -469,7 +491,8 @@ def convtr_t5(root, dev, sd_dec, B, split16, fps=5):
     rows5 = op_profile(ad5, xs5, B, 6, fps)
     launches, by, ev = kernel_table(rows5, B, fps)
     res = convtr_roofline(launches, None, ev, ev, B, fps) or {}
-    for k in ("frac_pipelined", "frac_rocprof_pipelined", "frac_rocprof_serial", "avg_launch_us_rocprof_pipelined", "avg_launch_us_rocprof_serial", "rocprof_stale", "traffic"):
+    for k in ("frac_pipelined", "frac_serial", "frac_events_pipelined", "avg_launch_us_pipelined", "avg_launch_us_serial", "avg_launch_us_events_pipelined",
+              "rocprof_stale", "traffic"):
         res.pop(k, None)                   # (the committed traces / PMC passes are of the single-frame headline schedule)
     us, kname = convtr_standalone(dev, sd_dec, B, fps, split16)
     b_alone = 4.0 * (64 * (100 * fps + 1) + 32 * 300 * fps) * B + 4.0 * 64 * 32 * 6

@@ -73,6 +73,16 @@ def _pipeline_run(ckpt_root, xs, steps):
     return torch.cat(zs, -1), torch.cat(idxs, -1), torch.cat(ys, -1)
 
 
+@pytest.fixture(autouse=True)
+def _bounded_oracle_threads():
+    """The oracle's ATen CPU convs are small: with every core of a 256-cpu GPU box in the intra-op pool a frame takes many times longer
+    than with a handful (profiles/r2_cpu_legs.md)."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(16, old))
+    yield
+    torch.set_num_threads(old)
+
+
 def test_chain_pipeline_soak_is_reproducible_and_matches_per_stream_oracles(gpu, ckpt_root):
     audio = np.stack([synth.synth_audio(SEED_AUDIO, s, STEPS * HOP) for s in range(B)])
     xs = [torch.from_numpy(np.ascontiguousarray(audio[:, j * HOP:(j + 1) * HOP]))[:, None, :].to(DEV) for j in range(STEPS)]   # as bench.py: contiguous batches

@@ -1,22 +1,31 @@
 #!/bin/bash
-# The round's rocprofv3 evidence, taken over the TIMED STEPS of the pipelined bench schedule (three HIP streams) at HEAD:
-#   tools/profile_round.sh <tag>      (through gpurun; results under gpurun_out/<tag>_*; copy what is judged into profiles/)
-# 1. kernel trace -> per-kernel steady-state durations (tools/trace_summary.py)
-# 2. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes -> HBM-side traffic per launch (tools/pmc_summary.py)
-# All three passes run `bench.py --pmc-markers` in the SAME schedule the headline is timed in (no --serial).
+# The round's rocprofv3 evidence, taken over the TIMED STEPS of the bench schedules at HEAD:
+#   tools/profile_round.sh <tag> [serial-only|no-pmc]   (through gpurun; results under gpurun_out/<tag>_*; copy what is judged into profiles/)
+# 1. kernel trace of the PIPELINED schedule (three HIP streams: what `value` is timed in) -> <tag>_kernel_stats_steady.csv
+# 2. kernel trace of `--serial` (one HIP stream, nothing else on the chip)               -> <tag>_kernel_stats_serial.csv
+#    (tools/trace_summary.py: per-kernel dispatch durations between the two --pmc-markers; bench.py quotes both as *_rocprof_*)
+# 3. FETCH_SIZE and WRITE_SIZE in two separate --pmc passes over the pipelined schedule -> HBM-side traffic per launch (tools/pmc_summary.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 tag=$1
+what=${2:-all}
 STEPS=40
-ARGS="--steps $STEPS --warmup 10 --pmc-markers --no-cpu-baseline --no-other-precision --no-op-profile --no-extra-configs --no-self-check"
+ARGS="--steps $STEPS --warmup 10 --pmc-markers --no-cpu-baseline --no-other-precision --no-op-profile --no-extra-configs --no-self-check --no-guarded --no-t5"
 mkdir -p $R/gpurun_out/$tag
-timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/$tag/trace -o p --output-format csv -- python $R/bench.py $ARGS > $R/gpurun_out/${tag}_trace.log 2>&1
-echo "trace rc=$?"
-python $R/tools/trace_summary.py $R/gpurun_out/$tag/trace $R/gpurun_out/${tag}_kernel_stats_steady.csv $STEPS | head -40
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/$tag/pmc_$c -o p --output-format csv -- python $R/bench.py $ARGS > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
-  echo "$c rc=$?"
-done
-python $R/tools/pmc_summary.py $R/gpurun_out/$tag $R/gpurun_out/${tag}_pmc_traffic.csv | head -40
+if [ "$what" != "serial-only" ]; then
+  timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/$tag/trace -o p --output-format csv -- python $R/bench.py $ARGS > $R/gpurun_out/${tag}_trace.log 2>&1
+  echo "trace rc=$?"
+  python $R/tools/trace_summary.py $R/gpurun_out/$tag/trace $R/gpurun_out/${tag}_kernel_stats_steady.csv $STEPS | head -40
+fi
+timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/$tag/trace_serial -o p --output-format csv -- python $R/bench.py $ARGS --serial > $R/gpurun_out/${tag}_trace_serial.log 2>&1
+echo "serial trace rc=$?"
+python $R/tools/trace_summary.py $R/gpurun_out/$tag/trace_serial $R/gpurun_out/${tag}_kernel_stats_serial.csv $STEPS | head -40
+if [ "$what" = "all" ]; then
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/$tag/pmc_$c -o p --output-format csv -- python $R/bench.py $ARGS > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
+    echo "$c rc=$?"
+  done
+  python $R/tools/pmc_summary.py $R/gpurun_out/$tag $R/gpurun_out/${tag}_pmc_traffic.csv | head -40
+fi
 find $R/gpurun_out/$tag -name "*.db" -delete 2>/dev/null
 find $R/gpurun_out/$tag -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
