@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr bool BIAS_LDS = C < 128 && !(C == 64 && (SMAX == 2 || WR > 0));    // bias of every conv staged in LDS -- unless the LDS is needed to the last KB for a second / third workgroup per CU
     constexpr int RING_BYTES = WR * 4096;
     constexpr bool BIAS_LATE = WR > 0 && !BIAS_LDS;
-    constexpr bool HIST_LATE = WR > 0 && WPS == 3 && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
+    constexpr bool HIST_LATE = (WR > 0 || ADK_RB16_HIST_LATE > 1) && WPS == 3 && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
                                                      // finish / ring-store pass instead of in front of it (16 registers less at the epilogue's peak)   // bias fetched BEHIND the MFMA loop (16 registers per lane would otherwise live through it)
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
@@ -672,13 +672,18 @@ int rb_streams_per_wg(int C, int batch, int t) {
 }
 
 // Slots of the shared LDS weight ring for this geometry (0: the waves stream their weights into registers, as in round 3).
-// 32 channels: the 4 waves of a workgroup share ONE m-tile -- a fragment crosses L2 -> CU once instead of four times; 64 channels: two
-// waves per m-tile -- once instead of twice.  128 channels: every wave has an m-tile of its own, nothing to share.
-// ADK_RB16_RING=0 switches it off (A/B); the variants below are the ones instantiated.
+// On for the 168-register variants (two n-tiles per wave, three workgroups per CU): with no weight fragments in registers -- and the
+// next conv's history rows requested behind the finish pass -- they spill 0-4 registers instead of 21-33 (each reload in an epilogue is
+// a vmcnt(0) round trip), and a fragment crosses L2 -> CU once per workgroup instead of twice (64 channels) / four times (32).
+// Measured, 256 streams (profiles/r4_ring_ab.md): vocoder stage 2 (64 ch) 176 -> 166 us, encoder block 1 64.7 -> 61.8 us, pipeline +1.5 %.
+// Off for the three-tile 32-channel variant (two workgroups per CU, no spills to begin with): there the per-group barrier costs more
+// than the weight stream did (vocoder stage 3 139 -> 148 us) -- ADK_RB16_RING=2 switches it on for A/B, =0 switches all rings off.
+// 128 channels: every wave has an m-tile of its own, nothing to share.
 int rb_ring_slots(int C, int ntw, int spw) {
     static const int on = rb_knob("ADK_RB16_RING", 1);
     if (!on) return 0;
-    if (C == 32 && (ntw == 2 || ntw == 3)) return ntw == 3 ? ADK_RB16_RING_SLOTS32 : 3;
+    if (C == 32 && ntw == 2) return 3;
+    if (C == 32 && ntw == 3 && on >= 2) return ADK_RB16_RING_SLOTS32;
     if (C == 64 && ntw == 2 && spw == 1) return 3;        // three 4 KiB slots is what three workgroups per CU leave room for
     return 0;
 }
