@@ -30,6 +30,14 @@ struct ConvArgs {
     int batch, t_out, n_total;      // n_total = batch * t_out GEMM columns
     int ktot;                       // taps * cin_g
     int* err = nullptr;             // sticky device flag word the launch reports to: its program's (adk_program_flags), or nullptr = the device-wide word
+    // "Shadow" rings (round 4, split-f16 stream-K kernel only): a second ring of the SAME geometry as `in` / `out` whose every 4-channel
+    // group (16 bytes, where the f32 ring holds 4 floats) holds the split-f16 operand form of act(x): [4 x f16 hi][4 x f16 lo], hi = f16(y),
+    // lo = f16((y - hi) * 2048), y = act(x) with the READERS' input activation.  Written once by the producer's epilogue (out_sh), it
+    // replaces the activation + split a consumer otherwise redoes for every staged element -- once per tap and per 64-row m-tile
+    // (11 x 4 times for the 256-channel grouped K11 convs).  Same values, bit for bit.
+    const float* in_sh = nullptr;   // shadow of the input ring (nullptr: stage from `in` and convert)
+    float* out_sh = nullptr;        // shadow of the output ring, to be written beside `out` (nullptr: none)
+    int sh_act = 0; float sh_slope = 0.f;      // activation the output shadow carries
 };
 inline int* conv_err_word(const ConvArgs& a);
 

@@ -100,6 +100,8 @@ struct SkArgs {
     long long total;      // tiles * nchunks
 };
 
+constexpr int kActPre = 100;   // ACT template value of the stream-K kernel: the staged pieces come from a shadow ring, already activated and split
+
 template <int ACT>
 __device__ __forceinline__ float act_in_apply(float x, float slope) {
     if (ACT == ADK_ACT_ELU) return x > 0.f ? x : expm1_neg(x);
@@ -169,6 +171,20 @@ __device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&ac
             if (a.up > 1) { const int ph = mg / a.cout_real; orow += ph; ocol = mg - ph * a.cout_real; }
             if (orow >= a.out_rows) orow -= a.out_rows;
             *reinterpret_cast<float4*>(outb + (size_t)orow * a.out_ch + ocol) = v;
+            if (CHECK && a.out_sh) {
+                // the readers' operand form of these 4 channels, once: act, split into f16 hi / lo*2048 (what lstore_piece computes per
+                // staged element otherwise) -- same 16-byte slot of the shadow ring as the floats above in theirs
+                const float x[4] = {act_apply(v.x, a.sh_act, a.sh_slope), act_apply(v.y, a.sh_act, a.sh_slope),
+                                    act_apply(v.z, a.sh_act, a.sh_slope), act_apply(v.w, a.sh_act, a.sh_slope)};
+                union { f16x4s h[2]; float4 f; } sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)x[e];
+                    sh.h[0][e] = h;
+                    sh.h[1][e] = (_Float16)((x[e] - (float)h) * kSkLoScale);
+                }
+                *reinterpret_cast<float4*>(a.out_sh + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + ocol) = sh.f;
+            }
         }
     }
     if (CHECK && bad) atomicOr(err, 8);
@@ -343,7 +359,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
     };
     auto lstore_piece = [&](int buf, const float4 (&rb)[RB], int rr) {
         float* Bb = Bs + buf * BN * LDK;
-        {
+        if constexpr (SPLIT && ACT == kActPre) {
+            // shadow ring: the 16 bytes ARE [4 halfs hi][4 halfs lo] of act(x) -- two 8-byte LDS stores, no arithmetic
+            union { float4 f; f16x4s h[2]; } u;
+            u.f = rb[rr];
+            unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + CPR * rr) * LDK) + 8 * quad;
+            *reinterpret_cast<f16x4s*>(d) = u.h[0];
+            *reinterpret_cast<f16x4s*>(d + 2 * KCC) = u.h[1];
+        } else {
             float4 v = rb[rr];
             if (!(SPLIT && (ADK_SK16_DBG & 2))) {
                 v.x = act_in_apply<ACT>(v.x, a.slope); v.y = act_in_apply<ACT>(v.y, a.slope);
@@ -796,6 +819,22 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
         }
     }
     const unsigned grid = (unsigned)((sk.G + 7) / 8 * 8);
+    if constexpr (SPLIT) {
+        if (a.in_sh) {
+            // the input ring has a shadow: stage the pre-activated, pre-split pieces from it (same geometry, same addressing)
+            static bool pre_attr_dev[kMaxDevices] = {};
+            bool& pre_attr = pre_attr_dev[current_device()];
+            if (lds > 64 * 1024 && !pre_attr) {
+                ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_sk_kernel<WGM, WGN, NJ, kActPre, SPLIT, KD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                pre_attr = true;
+            }
+            ConvArgs b = a;
+            b.in = a.in_sh;
+            hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, kActPre, SPLIT, KD>), dim3(grid), dim3(NT), lds, s, b, sk);
+            ADK_HIP_CHECK(hipGetLastError());
+            return ADK_OK;
+        }
+    }
     if (a.act_in == ADK_ACT_ELU)
         hipLaunchKernelGGL((conv_sk_kernel<WGM, WGN, NJ, ADK_ACT_ELU, SPLIT, KD>), dim3(grid), dim3(NT), lds, s, a, sk);
     else if (a.act_in == ADK_ACT_LEAKY)

@@ -99,6 +99,8 @@ static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
         if (!conv_rl_supported(a)) return fail(ADK_ERR_SHAPE, "conv: rows-in-LDS kernel needs stride 1, 32/64 channels per group, w_frag");
         return launch_conv_rl(a, s);
     }
+    if (a.out_sh && impl != ADK_IMPL_SPLIT16_SK)
+        return fail(ADK_ERR_STATE, "conv: an op that writes a shadow ring must run on the split-f16 stream-K kernel (impl = ADK_IMPL_SPLIT16_SK)");
     if (is_split16(impl)) {
         // split-f16 kernels (w_frag in the adk_pack_weights_split16 layout): the up-sampling streamer for its one layer shape,
         // rows-in-LDS when it fills the chip, else stream-K
@@ -329,6 +331,19 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             if (o.b_off >= 0 && (o.b_off % 4 || o.b_off + (long long)o.conv.groups * o.conv.cout_g > weights_floats))
                 return bail(ADK_ERR_SHAPE, "program_create: bias offset out of range");
             if (o.rate_out <= 0) return bail(ADK_ERR_SHAPE, "program_create: rate_out must be positive");
+            for (int side = 0; side < 2; ++side) {
+                const int sh = (side ? o.out_shadow : o.in_shadow) - 1, of = side ? o.out_ring : o.in_ring;
+                if (sh < 0) continue;
+                if (!ring_ok(sh) || sh == of || rings[sh].external >= 0 || rings[of].external >= 0)
+                    return bail(ADK_ERR_ARG, "program_create: a shadow ring must be an arena ring of its own, shadowing an arena ring");
+                if (rings[sh].channels != rings[of].channels || rings[sh].hist != rings[of].hist || rings[sh].rate != rings[of].rate)
+                    return bail(ADK_ERR_SHAPE, "program_create: a shadow ring must have the geometry of its ring");
+                if (!is_split16(o.impl)) return bail(ADK_ERR_ARG, "program_create: shadow rings are for ADK_IMPL_SPLIT16* ops");
+                if (side && o.impl != ADK_IMPL_SPLIT16_SK) return bail(ADK_ERR_ARG, "program_create: an op that writes a shadow ring needs impl = ADK_IMPL_SPLIT16_SK");
+                if (side && (o.out_ch_off != 0 || o.conv.cout_real != rings[of].channels))
+                    return bail(ADK_ERR_SHAPE, "program_create: an op that writes a shadow ring must write whole rows");
+                if (side && (o.shadow_act < 0 || o.shadow_act > ADK_ACT_LEAKY)) return bail(ADK_ERR_ARG, "program_create: shadow_act must be NONE, ELU or LeakyReLU");
+            }
             if (o.conv.hist > rings[o.in_ring].hist) return bail(ADK_ERR_SHAPE, "program_create: op needs more history than its ring keeps");
         } else if (o.kind == ADK_OP_RING_WRITE) {
             if (!ring_ok(o.out_ring) || o.ext_src < 0) return bail(ADK_ERR_ARG, "program_create: ring_write needs out_ring and ext_src");
@@ -397,7 +412,11 @@ static int op_conv_args(adk_program* p, int i, int frames, void* const* ext, Con
     if (o.res_ring >= 0) res = view_of(p, o.res_ring, frames, ext, o.res_ch_off);
     const int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
     a.err = p->flags;
-    return rc;
+    if (rc != ADK_OK) return rc;
+    // shadow rings (adk_op_desc.in_shadow / out_shadow; geometry checked against their rings at create time): they move with their rings
+    if (o.in_shadow > 0) a.in_sh = view_of(p, o.in_shadow - 1, frames, ext, 0).base;
+    if (o.out_shadow > 0) { a.out_sh = view_of(p, o.out_shadow - 1, frames, ext, 0).base; a.sh_act = o.shadow_act; a.sh_slope = o.shadow_slope; }
+    return ADK_OK;
 }
 
 // Can ops i, i+1 run as one launch for a `frames`-hop step?  0: no; 1: a residual unit (conv -> 1x1 + residual: conv_rl16 FUSE);
@@ -410,6 +429,7 @@ static int op_pair_kind(adk_program* p, int i, int frames, void* const* ext, Con
     const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
     if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16 || o2.impl != ADK_IMPL_SPLIT16) return 0;
     if (o2.in_ring != o1.out_ring || p->rings[o1.out_ring].external >= 0) return 0;
+    if (o1.out_shadow > 0 || o2.out_shadow > 0) return 0;        // (only the stream-K kernel's epilogue writes shadow rings)
     if (op_conv_args(p, i, frames, ext, a1) != ADK_OK || op_conv_args(p, i + 1, frames, ext, a2) != ADK_OK) return 0;
     if (g_use_rl && conv_rl16_fusable(a1, a2)) return 1;
     if (g_use_ou && g_use_up && conv_ou16_fusable(a1, a2)) return 2;
@@ -429,7 +449,7 @@ static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext
     if ((long long)p->batch * p->ops[i].conv.groups < g_chain_min_blocks) return false;
     for (int k = 0; k < n; ++k) {
         const adk_op_desc& o = p->ops[i + k];
-        if (o.kind != ADK_OP_CONV || o.impl != ADK_IMPL_SPLIT16) return false;
+        if (o.kind != ADK_OP_CONV || o.impl != ADK_IMPL_SPLIT16) return false;      // (ops that write a shadow ring carry ADK_IMPL_SPLIT16_SK: never fused)
         if (k > 0 && o.chain > 1) return false;
         if (k + 1 < n && (p->rings[o.out_ring].external >= 0 || p->ops[i + k + 1].in_ring != o.out_ring)) return false;
         if (op_conv_args(p, i + k, frames, ext, c[k]) != ADK_OK) return false;

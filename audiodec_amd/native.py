@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
@@ -41,7 +41,8 @@ class OpDesc(C.Structure):
                 ("in_ch_off", C.c_int32), ("out_ch_off", C.c_int32), ("res_ch_off", C.c_int32),
                 ("rate_out", C.c_int32), ("conv", ConvDesc), ("w_off", C.c_int64), ("wf_off", C.c_int64), ("b_off", C.c_int64),
                 ("mean_off", C.c_int64), ("scale_off", C.c_int64), ("ext_src", C.c_int32),
-                ("mean_rings", C.c_int32 * 4), ("n_mean", C.c_int32), ("impl", C.c_int32), ("fuse_next", C.c_int32), ("chain", C.c_int32)]
+                ("mean_rings", C.c_int32 * 4), ("n_mean", C.c_int32), ("impl", C.c_int32), ("fuse_next", C.c_int32), ("chain", C.c_int32),
+                ("in_shadow", C.c_int32), ("out_shadow", C.c_int32), ("shadow_act", C.c_int32), ("shadow_slope", C.c_float)]
 
 
 # every symbol include/audiodec_hip.h declares: (restype, argtypes)

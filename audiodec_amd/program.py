@@ -111,6 +111,8 @@ def mfma_eligible(cin_g, cout_g, groups):
 
 FUSE_RES_UNITS = os.environ.get("ADK_FUSE", "1") != "0"      # ADK_FUSE=0: every residual unit as two launches (A/B, cross-checks)
 FUSE_CHAINS = os.environ.get("ADK_CHAIN", "1") != "0"        # ADK_CHAIN=0: residual chains (a block's three units) op by op, not as one launch
+SHADOW_RINGS = os.environ.get("ADK_SHADOW", "1") != "0"      # ADK_SHADOW=0: no shadow rings (every stream-K conv activates + splits what it stages; A/B, cross-checks)
+SHADOW_MIN_CH = 128                                           # channels per group from which a conv is always a stream-K launch (the rows / chain kernels take 32 / 64, chains 128)
 
 
 class Blob:
@@ -146,6 +148,9 @@ class Builder:
         self.rings, self.ops, self.op_names = [], [], []
         self.scratch = {}
         self.flops_per_frame = 0
+        self._auto = []                 # per op: lowered with impl = AUTO (the shape, not the arithmetic of this builder, decides about shadow rings)
+        self._shadows_done = False
+        self.shadow_of = {}             # ring id -> id of its shadow ring
 
     def ring(self, channels, hist, rate, external=-1):
         self.rings.append(dict(channels=channels, hist=hist, rate=rate, external=external))
@@ -172,6 +177,7 @@ class Builder:
         op.w_off, op.wf_off, op.b_off = -1, -1, -1
         op.rate_out = self.rings[out_ring]["rate"]
         self.ops.append(op)
+        self._auto.append(False)
         self.op_names.append("ring_write")
 
     def mean(self, src_rings, out_ring):
@@ -186,6 +192,7 @@ class Builder:
             op.mean_rings[k] = r
         op.rate_out = self.rings[out_ring]["rate"]
         self.ops.append(op)
+        self._auto.append(False)
         self.op_names.append("mean")
 
     def hist_replicate(self, ring):
@@ -198,6 +205,7 @@ class Builder:
         op.ext_src = -1
         op.rate_out = self.rings[ring]["rate"]
         self.ops.append(op)
+        self._auto.append(False)
         self.op_names.append("hist_replicate")
 
     def conv(self, name, in_ring, out_ring, act_in=ACT_NONE, slope=0.0, act_out=ACT_NONE, res_ring=-1,
@@ -235,6 +243,7 @@ class Builder:
         op.in_ch_off = op.out_ch_off = op.res_ch_off = 0
         op.rate_out = rate_out
         op.conv = d
+        auto = impl == IMPL_AUTO
         if self.split16 and impl == IMPL_AUTO and split16_eligible(d.cin_g, d.cout_g, d.groups):
             impl = native.IMPL_SPLIT16
             op.w_off, op.wf_off = -1, self.blob.add(pack_split16(packed, d.groups))
@@ -249,9 +258,74 @@ class Builder:
         op.fuse_next = 1 if fuse_next else 0
         op.chain = 0
         self.ops.append(op)
+        self._auto.append(auto)
         self.op_names.append(name)
         self.flops_per_frame += 2 * packed.numel() * rate_out
         return op
+
+    def assign_shadows(self):
+        """Give the rings between two stream-K convs a SHADOW ring (adk_op_desc.in_shadow / out_shadow): the producer's epilogue stores,
+        beside every 4 floats, their split-f16 operand form [4 x f16 hi][4 x f16 lo] of act(x); the consumer stages those 16 bytes as
+        they are.  Without it the consumer re-applies the activation and the split to every element it stages -- once per tap and per
+        64-row tile of output channels: 44 times per element in the 256-channel grouped K11 convs of a v1 vocoder's first stage.
+
+        A ring qualifies when EVERY op that writes it and at least one conv that reads it are certain to run on the stream-K kernel in
+        the split-f16 lowering: AUTO-lowered convs with >= SHADOW_MIN_CH channels per group (the rows kernels take 32 / 64), outside a
+        chain the chain kernel takes (<= 128 channels) and outside a fusable pair; the qualifying readers must agree on the input
+        activation.  The decision looks at shapes only, so that the exact-f32 twin of a program (HipProgram.demote) lays out the same
+        arena: it allocates the shadow rings and leaves them alone.  Not for offline programs (their history replicate op would have to
+        replicate shadows too).  Called once, by HipProgram, after the last op was added."""
+        if self._shadows_done:
+            return
+        self._shadows_done = True
+        if self.offline or not SHADOW_RINGS:
+            return
+        n = len(self.ops)
+        in_chain, in_pair = set(), set()
+        for i, op in enumerate(self.ops):
+            if op.kind != OP_CONV:
+                continue
+            if op.chain >= 2:
+                in_chain.update(range(i, i + op.chain))
+            if op.fuse_next and i + 1 < n and self.ops[i + 1].kind == OP_CONV and self.ops[i + 1].conv.cin_g in (32, 64):
+                in_pair.update((i, i + 1))      # residual unit on the rows kernel / conv_out + the 64-channel transposed conv (conv_ou16)
+
+        def streamk(i):
+            op = self.ops[i]
+            if op.kind != OP_CONV or not self._auto[i] or i in in_pair:
+                return False
+            d = op.conv
+            if not split16_eligible(d.cin_g, d.cout_g, d.groups) or d.cin_g < SHADOW_MIN_CH:
+                return False
+            return not (i in in_chain and d.cin_g <= 128)
+
+        for rid, r in enumerate(list(self.rings)):
+            if r["external"] >= 0:
+                continue
+            writers = [i for i, op in enumerate(self.ops) if op.out_ring == rid and op.kind != OP_HIST_REPLICATE]
+            readers = [i for i, op in enumerate(self.ops) if op.kind == OP_CONV and op.in_ring == rid]
+            if not writers or not all(streamk(i) for i in writers):
+                continue
+            if any(self.ops[i].out_ch_off != 0 or self.ops[i].conv.cout_real != r["channels"] for i in writers):
+                continue                        # (a shadow is complete only if its writers write whole rows)
+            sk_readers = [i for i in readers if streamk(i)]
+            acts = {(self.ops[i].conv.act_in, float(self.ops[i].conv.act_in_slope)) for i in sk_readers}
+            if not sk_readers or len(acts) != 1:
+                continue
+            act, slope = next(iter(acts))
+            if act not in (ACT_NONE, ACT_ELU, ACT_LEAKY):
+                continue
+            sh = self.ring(r["channels"], r["hist"], r["rate"])
+            self.rings[sh]["shadow_of"] = rid
+            self.shadow_of[rid] = sh
+            if not self.split16:
+                continue                        # exact-f32 lowering: same arena layout, nobody touches the shadow
+            for i in writers:
+                op = self.ops[i]
+                op.out_shadow, op.shadow_act, op.shadow_slope = sh + 1, act, slope
+                op.impl = native.IMPL_SPLIT16_SK
+            for i in sk_readers:
+                self.ops[i].in_shadow = sh + 1
 
 
 def _act_of(params, default="ELU"):
@@ -469,6 +543,7 @@ class HipProgram:
         self.graph_requested = bool(graph)
         self.demoted = False
         self.workgroups = 0
+        builder.assign_shadows()
         if graph:
             for r in builder.rings:
                 if r["external"] < 0:

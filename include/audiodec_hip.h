@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 11
+#define ADK_ABI_VERSION 12
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -247,6 +247,16 @@ typedef struct {
                                             an encoder / decoder block, encoder.py:76-81, decoder.py:73-78).  The runner may launch all n as
                                             ONE kernel (csrc/conv_rb16.hip: activations resident in LDS; an intermediate ring then receives
                                             only the rows later calls need as history).  0 / 1: no chain starts here */
+    int32_t in_shadow, out_shadow;       /* 1 + id of the SHADOW ring of in_ring / out_ring, 0 = none (ADK_IMPL_SPLIT16* ops only).  A shadow
+                                            ring has the geometry of its ring (channels, hist, rate) and holds, per 4-channel group of a row
+                                            (16 bytes, where the ring holds 4 floats), [4 x f16 hi][4 x f16 lo] of act(x): the split-f16 operand
+                                            form the readers would otherwise recompute for every element they stage, once per tap and per
+                                            64-row tile of outputs.  out_shadow: this op writes it beside its output (stream-K kernel only:
+                                            give such an op impl = ADK_IMPL_SPLIT16_SK; every op that writes the ring must carry it);
+                                            in_shadow: the stream-K kernel stages from it instead of converting (other kernels ignore it:
+                                            the ring itself is always complete).  Results are bit-identical with and without. */
+    int32_t shadow_act;                  /* ADK_ACT_* the out_shadow carries = the act_in of the ring's readers */
+    float shadow_slope;
 } adk_op_desc;
 
 /* rows of ring i = hist + max_frames * rate (arena rings). */

@@ -46,7 +46,8 @@ def test_abi_version_and_struct_sizes(lib):
     assert C.sizeof(native.RingView) == 24
     assert C.sizeof(native.ConvDesc) == 80
     assert C.sizeof(native.RingDesc) == 24
-    assert C.sizeof(native.OpDesc) == 192 and native.OpDesc.chain.offset == 184 and native.OpDesc.fuse_next.offset == 180
+    assert C.sizeof(native.OpDesc) == 208 and native.OpDesc.chain.offset == 184 and native.OpDesc.fuse_next.offset == 180
+    assert native.OpDesc.in_shadow.offset == 188 and native.OpDesc.shadow_slope.offset == 200
     # ... and what gcc makes of the header itself (the header is C: a maintainer's cgo / ctypes stub sees these numbers)
     import os, subprocess, tempfile
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
@@ -57,7 +58,7 @@ def test_abi_version_and_struct_sizes(lib):
                      'sizeof(adk_conv_desc), sizeof(adk_ring_desc), sizeof(adk_op_desc), offsetof(adk_op_desc, chain), ADK_ABI_VERSION);return 0;}\n')
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", os.path.join(td, "sz")], check=True)
         out = subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout.split()
-    assert [int(v) for v in out] == [24, 80, 24, 192, 184, native.ABI_VERSION]
+    assert [int(v) for v in out] == [24, 80, 24, 208, 184, native.ABI_VERSION]
 
 
 def test_argument_validation_without_device(lib):

@@ -442,3 +442,61 @@ def test_survey_configs_2_and_3_match_oracle_at_their_stream_counts(gpu, ckpt_ro
     assert res["ok"], res
     from audiodec_amd import native
     assert native.device_flags() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# shadow rings (adk_op_desc.in_shadow / out_shadow): the producer's epilogue stores the split-f16 operand form once, the
+# consumer stages it as it is -- the same values, so the outputs must not move by a bit
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,B,max_frames,calls", [("vctk_v1", 256, 1, [1, 1, 1, 1, 1, 1]), ("vctk_sym", 33, 3, [1, 3, 2, 1, 3]), ("vctk_v0", 5, 2, [2, 1, 2])])
+def test_shadow_rings_are_bit_identical(gpu, ckpt_root, monkeypatch, model, B, max_frames, calls):
+    """Two models, one lowered with shadow rings and one without (ADK_SHADOW=0's switch), the same calls: ragged multi-frame steps
+    (ring wrap-around), a per-stream reset to the warmed-up state in the middle, a full reset_buffer at the end.  Reference
+    semantics are untouched (CausalConv1d.inference, layers/conv_layer.py:153-156: the state ring IS the pad_buffer; the shadow is a
+    second encoding of the same rows): latent, indices and waveform are compared bit for bit."""
+    from audiodec_amd import program
+    seed = 1337
+    monkeypatch.setattr(program, "SHADOW_RINGS", True)
+    ad1 = load_audiodec(ckpt_root, model, seed, B, max_frames, True)
+    progs = [ad1.tx_encoder._encoder()] + (list(ad1.decoder._decoder_stages()) if hasattr(ad1.decoder, "_decoder_stages") else [ad1.decoder._decoder()])
+    n_in = sum(1 for pr in progs for i in range(pr.n_ops) if pr._ops[i].in_shadow)
+    n_out = sum(1 for pr in progs for i in range(pr.n_ops) if pr._ops[i].out_shadow)
+    assert n_in >= 7 and n_out >= 7, (n_in, n_out)              # the 256-channel blocks of encoder and decoder at least
+    for pr in progs:
+        for i in range(pr.n_ops):
+            if pr._ops[i].out_shadow:
+                assert pr.describe_op(i, 1).startswith("conv_sk16<"), (pr.op_names[i], pr.describe_op(i, 1))
+    monkeypatch.setattr(program, "SHADOW_RINGS", False)
+    ad0 = load_audiodec(ckpt_root, model, seed, B, max_frames, True)
+    progs0 = [ad0.tx_encoder._encoder()] + (list(ad0.decoder._decoder_stages()) if hasattr(ad0.decoder, "_decoder_stages") else [ad0.decoder._decoder()])
+    assert not any(pr._ops[i].in_shadow or pr._ops[i].out_shadow for pr in progs0 for i in range(pr.n_ops))
+    assert sum(pr.n_rings for pr in progs) > sum(pr.n_rings for pr in progs0)
+    total = sum(calls) * HOP
+    audio = np.stack([synth.synth_audio(777, s, total) for s in range(B)])
+
+    def run(ad):
+        outs, pos = [], 0
+        with torch.no_grad():
+            for k, f in enumerate(calls):
+                if k == len(calls) // 2:
+                    for g_ in (ad.tx_encoder, ad.decoder):
+                        g_.reset_stream(B - 1, warm=True)       # history rows of ring AND shadow rewritten from the captured state
+                x = torch.from_numpy(audio[:, pos:pos + f * HOP].copy())[:, None, :].to(DEV)
+                pos += f * HOP
+                z = ad.tx_encoder.encode(x)
+                idx = ad.tx_encoder.quantize(z)
+                y = ad.decoder.decode(ad.rx_encoder.lookup(idx))
+                outs.append((z.clone(), idx.clone(), y.clone()))
+            ad.tx_encoder.reset_buffer(); ad.decoder.reset_buffer()
+            x = torch.from_numpy(audio[:, :HOP].copy())[:, None, :].to(DEV)
+            z = ad.tx_encoder.encode(x)
+            outs.append((z.clone(), ad.tx_encoder.quantize(z).clone(), ad.decoder.decode(ad.rx_encoder.lookup(ad.tx_encoder.quantize(z))).clone()))
+        return outs
+
+    o1, o0 = run(ad1), run(ad0)
+    for k, ((z1, i1, y1), (z0, i0, y0)) in enumerate(zip(o1, o0)):
+        assert torch.equal(z1, z0), f"call {k}: latent differs by {float((z1 - z0).abs().max()):.3e}"
+        assert torch.equal(i1, i0), f"call {k}: indices differ"
+        assert torch.equal(y1, y0), f"call {k}: waveform differs by {float((y1 - y0).abs().max()):.3e}"
+    from audiodec_amd import native
+    assert native.device_flags() == 0
