@@ -173,17 +173,22 @@ __device__ __forceinline__ void sk_epilogue(const ConvArgs& a, const f32x16 (&ac
             *reinterpret_cast<float4*>(outb + (size_t)orow * a.out_ch + ocol) = v;
             if (CHECK && a.out_sh) {
                 // the readers' operand form of these 4 channels, once: act, split into f16 hi / lo*2048 (what lstore_piece computes per
-                // staged element otherwise) -- same 16-byte slot of the shadow ring as the floats above in theirs
+                // staged element otherwise).  Shadow row layout: per 8 channels 32 bytes, [8 x f16 hi][8 x f16 lo] -- an MFMA B fragment
+                // (8 consecutive k of one column) is then ONE aligned 16-byte piece, for the stream-K kernel's staging as for the
+                // DMA-fed kernel below; this lane's 4 channels are half of such a group: two 8-byte stores
                 const float x[4] = {act_apply(v.x, a.sh_act, a.sh_slope), act_apply(v.y, a.sh_act, a.sh_slope),
                                     act_apply(v.z, a.sh_act, a.sh_slope), act_apply(v.w, a.sh_act, a.sh_slope)};
-                union { f16x4s h[2]; float4 f; } sh;
+                f16x4s hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const _Float16 h = (_Float16)x[e];
-                    sh.h[0][e] = h;
-                    sh.h[1][e] = (_Float16)((x[e] - (float)h) * kSkLoScale);
+                    hi[e] = h;
+                    lo[e] = (_Float16)((x[e] - (float)h) * kSkLoScale);
                 }
-                *reinterpret_cast<float4*>(a.out_sh + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + ocol) = sh.f;
+                unsigned char* srow = reinterpret_cast<unsigned char*>(a.out_sh + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff);
+                unsigned char* sp = srow + (size_t)(ocol >> 3) * 32 + (ocol & 4) * 2;           // group ocol / 8, first or second half of its hi block
+                *reinterpret_cast<f16x4s*>(sp) = hi;
+                *reinterpret_cast<f16x4s*>(sp + 16) = lo;
             }
         }
     }
@@ -360,12 +365,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
     auto lstore_piece = [&](int buf, const float4 (&rb)[RB], int rr) {
         float* Bb = Bs + buf * BN * LDK;
         if constexpr (SPLIT && ACT == kActPre) {
-            // shadow ring: the 16 bytes ARE [4 halfs hi][4 halfs lo] of act(x) -- two 8-byte LDS stores, no arithmetic
-            union { float4 f; f16x4s h[2]; } u;
-            u.f = rb[rr];
-            unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + CPR * rr) * LDK) + 8 * quad;
-            *reinterpret_cast<f16x4s*>(d) = u.h[0];
-            *reinterpret_cast<f16x4s*>(d + 2 * KCC) = u.h[1];
+            // shadow ring: this thread's 16 bytes ARE 8 halfs of the operand form -- the hi halfs of an 8-channel group (even piece) or
+            // its lo halfs (odd piece): one 16-byte LDS store, no arithmetic
+            unsigned char* d = reinterpret_cast<unsigned char*>(Bb + (srow + CPR * rr) * LDK) + 16 * (quad >> 1) + ((quad & 1) ? 2 * KCC : 0);
+            *reinterpret_cast<float4*>(d) = rb[rr];
         } else {
             float4 v = rb[rr];
             if (!(SPLIT && (ADK_SK16_DBG & 2))) {
@@ -684,6 +687,234 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
 #endif
 }
 
+
+// ================================================================================================
+// conv_gk16 -- 128 x 128 tiles, BOTH operands through LDS by LDS-DMA, split-f16 arithmetic (round 4).
+//
+// The stream-K kernel above gives every wave a 32 x 32 block of its workgroup's 64 x 64 tile: per 64-deep chunk a workgroup requests
+// 32 KiB of weight fragments (each wave its own, two waves the same ones) and 16 KiB of activations for 48 MFMAs -- 1 KiB per MFMA.
+// For the wide layers (256 channels per group, K up to 2816: the first stage of a v1 vocoder, 5.5 GFLOP per conv at 256 streams)
+// that is ~20 TB/s of L2 reads chip-wide for 137 TFLOP/s: the kernel sits on the L2, whatever the loop does (profiles/r2_sk16_analysis.md).
+// With a SHADOW ring as input (adk_op_desc.in_shadow: the operand form of act(x) is already in memory) nothing has to pass through
+// registers on its way to LDS any more, so the tile can grow to what the accumulators allow:
+//   * one workgroup = 4 waves = a 128 x 128 tile of one group, each wave a 64 x 64 quarter (2 x 2 MFMA tiles: 128 accumulator registers
+//     for the main and the cross sums); 12 MFMAs per wave and 16-k step on 4 + 4 fragment reads; 64 KiB per chunk for 192 MFMAs --
+//     a third of the stream-K kernel's traffic per MFMA;
+//   * per 64-deep chunk the workgroup copies 32 KiB of packed weight fragments (lane-linear, as they are) and 32 KiB of shadow rows
+//     (128 columns x 256 bytes = the 64 channels of one tap as [8 hi][8 lo] groups) global -> LDS with global_load_lds_dwordx4, 16
+//     pieces of 1 KiB per wave, double buffered: the pieces of chunk c + 1 are issued between the MFMA steps of chunk c;
+//   * the B image is [column][16 slots of 16 bytes] with slot ^= column & 15 -- the 16 lanes of a ds_read_b128 group sit in 16
+//     different columns and would otherwise all hit the same banks; LDS-DMA writes lane-linear, so the swizzle is applied to the
+//     per-lane SOURCE address of the copy (cdna_hip_programming.md rule 21);
+//   * K is split evenly over `S` workgroups per tile (tiles x S ~ the number of CUs); every part writes its 128 x 128 partial sums
+//     write-through to the workspace and bumps the tile's counter; the part that arrives LAST adds all parts in part order -- a fixed
+//     order, so the result does not depend on who was last -- runs the epilogue (the stream-K kernel's: bias, residual, output
+//     shadow) and puts the counter back to 0.  Nobody ever waits for anybody.
+// Per accumulator the order is that of the other split kernels (hi*hi | hi*lo, lo*hi; main + cross / 2048); where K is cut differs
+// from the stream-K kernel, so results agree with it to f32 round-off, not bit for bit (as for any two stream-K splits).
+struct GkArgs {
+    float* ws; unsigned ws_bytes;
+    unsigned* counters;   // [tiles]: parts of the tile that have published (0 between launches)
+    int S;                // K parts per tile
+    int G;                // tiles * S work items
+    int m_tiles, n_tiles, nchunks;
+    int cpt;              // 64-channel blocks per tap = cin_g / 64
+    int kgroups;          // 8-k fragments per 32-row m-tile (K is a multiple of 64 here)
+    int mt32_per_g;
+    float inv_t_out;
+    int* err;
+};
+
+constexpr int GK_BUF = 32 * 1024;                       // one operand, one chunk
+
+#define GK_DMA16(gptr, m0val) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                                                            : "=&s"(m0_keep_) : "v"(gptr), "s"(m0val) : "memory"); } while (0)
+
+__global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gks[];      // [A0 | A1 | B0 | B1], 32 KiB each, + 16 bytes
+    unsigned& last_sh = *reinterpret_cast<unsigned*>(gks + 4 * GK_BUF);       // (no static __shared__ next to a dynamic region of this size: it would shift its base off 16 bytes)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // XCD-contiguous work items: the parts of a tile, and the tiles of a group, share an L2
+    const int per_xcd = (gk.G + 7) >> 3;
+    const int r = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (r >= gk.G) return;
+    const int tile = r / gk.S, part = r - tile * gk.S;
+    const int mt = tile % gk.m_tiles;
+    const int rest = tile / gk.m_tiles;
+    const int nt = rest % gk.n_tiles;
+    const int g = rest / gk.n_tiles;
+    const int c0 = (part * gk.nchunks) / gk.S, c1 = ((part + 1) * gk.nchunks) / gk.S;
+
+    typedef unsigned char __attribute__((address_space(3)))* lds_u8_t;
+    const unsigned lds0 = (unsigned)(size_t)(lds_u8_t)gks;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    // ---- DMA sources.  A: this wave copies m-tile32 `wave` of the tile: 8 KiB per chunk, contiguous in the packed weights ----
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wfrag) +
+                                ((size_t)(g * gk.mt32_per_g + mt * 4 + wave) * gk.kgroups) * 1024u + lane16;
+    // B: piece p of this wave = columns 4 * (8 * wave + p) .. + 3 of the tile, 256 bytes each; lane -> (column, 16-byte slot)
+    const unsigned row_bytes = (unsigned)a.in_ch * 4u;
+    const unsigned ring_bytes = (unsigned)a.in_rows * row_bytes;
+    const unsigned dil_bytes = (unsigned)a.dilation * row_bytes;
+    const unsigned char* bsrc[8];          // column base (stream, group, channel offset) + slot of this lane
+    unsigned rowb[8];                      // ring row of tap 0 (bytes)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int col = 4 * (8 * wave + p) + (lane >> 4);
+        int n = nt * 128 + col;
+        if (n >= a.n_total) n = a.n_total - 1;              // (columns past the end: computed on a valid column, never stored)
+        const int b = fast_div(n, a.t_out, gk.inv_t_out), t = n - b * a.t_out;
+        int row = a.in_row0 + t * a.stride;
+        if (row >= a.in_rows) row -= a.in_rows;
+        rowb[p] = (unsigned)row * row_bytes;
+        const unsigned slot = (unsigned)((lane & 15) ^ (col & 15));
+        bsrc[p] = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * ring_bytes + (size_t)(a.in_choff + g * a.in_gstride) * 4u + slot * 16u;
+    }
+    auto issue_a = [&](int c, int buf, int p) __attribute__((always_inline)) {
+        GK_DMA16(wsrc + (size_t)c * 8192u + (size_t)p * 1024u, lds0 + (unsigned)buf * GK_BUF + (unsigned)wave * 8192u + (unsigned)p * 1024u);
+    };
+    // (tap, 64-channel block) of the chunk whose pieces are being issued: wave-uniform, advanced once per chunk
+    int tap_i = c0 / gk.cpt, cblk_i = c0 - tap_i * gk.cpt;
+    auto issue_b = [&](int buf, int p) __attribute__((always_inline)) {
+        unsigned rb = rowb[p] + (unsigned)tap_i * dil_bytes;
+        if (rb >= ring_bytes) rb -= ring_bytes;
+        GK_DMA16(bsrc[p] + rb + (unsigned)cblk_i * 256u, lds0 + 2u * GK_BUF + (unsigned)buf * GK_BUF + (unsigned)(8 * wave + p) * 1024u);
+    };
+    auto next_chunk = [&]() __attribute__((always_inline)) { if (++cblk_i == gk.cpt) { cblk_i = 0; ++tap_i; } };
+
+    f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
+
+    // ---- prologue: chunk c0 into buffer 0 ----
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { issue_a(c0, 0, p); issue_b(0, p); }
+    next_chunk();
+
+    // this lane's fragment addresses (bytes from the start of an operand buffer)
+    const unsigned a_off = (unsigned)(wm * 2) * 8192u + lane16;                           // + i * 8192 + (2 * st + half) * 1024
+    const unsigned x15 = (unsigned)(l31 & 15);
+    const unsigned b_off = (unsigned)(wn * 64 + l31) * 256u;                              // + jn * 32 * 256 + slot * 16
+
+    for (int c = c0; c < c1; ++c) {
+        const int buf = (c - c0) & 1;
+        // my pieces of chunk c have landed, and so have everybody's; all waves are done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned char* Ab = gks + buf * GK_BUF + a_off;
+        const unsigned char* Bb = gks + 2 * GK_BUF + buf * GK_BUF + b_off;
+        const bool more = c + 1 < c1;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            f16x8s ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8s*>(Ab + i * 8192 + (2 * st) * 1024);
+                al[i] = *reinterpret_cast<const f16x8s*>(Ab + i * 8192 + (2 * st + 1) * 1024);
+            }
+            const unsigned hs = ((unsigned)(4 * st + 2 * lh) ^ x15) * 16u, ls = ((unsigned)(4 * st + 2 * lh + 1) ^ x15) * 16u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8s*>(Bb + j * 32 * 256 + hs);
+                bl[j] = *reinterpret_cast<const f16x8s*>(Bb + j * 32 * 256 + ls);
+            }
+            // the next chunk's pieces, four per step, between this step's fragment reads and its MFMAs
+            if (more) { issue_a(c + 1, buf ^ 1, 2 * st); issue_a(c + 1, buf ^ 1, 2 * st + 1); issue_b(buf ^ 1, 2 * st); issue_b(buf ^ 1, 2 * st + 1); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+        }
+        next_chunk();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(accx[i][j][e], kSkLoInv, acc[i][j][e]);
+
+    if (gk.S > 1) {
+        // publish this part's sums (write-through), count it in, and leave -- unless it was the last one of its tile
+        const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(gk.ws, 0, gk.ws_bytes, 0x00020000);
+        const unsigned wbase = ((unsigned)r * 256u + (unsigned)tid) * 256u;               // 64 floats per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    u32x4 v;
+                    v.x = __float_as_uint(acc[i][j][4 * e4]); v.y = __float_as_uint(acc[i][j][4 * e4 + 1]);
+                    v.z = __float_as_uint(acc[i][j][4 * e4 + 2]); v.w = __float_as_uint(acc[i][j][4 * e4 + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)((i * 2 + j) * 64 + e4 * 16), 0, 16 /* sc1 */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) last_sh = __hip_atomic_fetch_add(gk.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (last_sh != (unsigned)(gk.S - 1)) return;
+        // last arriver: every part (this one's from its registers) in part order
+        f32x16 tot[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tot[i][j][e] = 0.f;
+        for (int sp = 0; sp < gk.S; ++sp) {
+            if (sp == part) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) tot[i][j][e] += acc[i][j][e];
+            } else {
+                const unsigned rbase = ((unsigned)(tile * gk.S + sp) * 256u + (unsigned)tid) * 256u;
+                u32x4 pv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, rbase + (unsigned)(q * 16), 0, 16 /* sc1 */);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const u32x4 v = pv[(i * 2 + j) * 4 + e4];
+                            tot[i][j][4 * e4] += __uint_as_float(v.x); tot[i][j][4 * e4 + 1] += __uint_as_float(v.y);
+                            tot[i][j][4 * e4 + 2] += __uint_as_float(v.z); tot[i][j][4 * e4 + 3] += __uint_as_float(v.w);
+                        }
+            }
+        }
+        if (tid == 0) __hip_atomic_store(gk.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        sk_epilogue<2, true>(a, acc[i], g, (mt * 4 + wm * 2 + i) * 32, nt * 128 + wn * 64, lane, gk.err);
+}
+
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
 // lane (i = lane&31, h = lane>>5) holds W[32*mt + i][8*kg + 4*h + 0..3]; rows >= cout_g and the K
 // tail (K is padded to a multiple of 64) are zero.
@@ -888,7 +1119,8 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
     }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);
     if (flags_offset) *flags_offset = part;
-    return part + (size_t)2 * 256 * g_occ * sizeof(unsigned);       // flags for up to twice the resident workgroups (oversubscribed plans)
+    return part + (size_t)2 * 256 * g_occ * sizeof(unsigned)        // flags for up to twice the resident workgroups (oversubscribed plans)
+           + (size_t)1024 * sizeof(unsigned);                       // ... and the per-tile arrival counters of conv_gk16 (kGkCounters; zero between launches)
 }
 
 int conv_mfma_pick(const ConvArgs& a) {
@@ -928,9 +1160,84 @@ int conv_sk16_pick(const ConvArgs& a) {
     return (a.cout_g % 64 == 0) ? 2 : 4;
 }
 
+
+// ---- conv_gk16 host side ----
+constexpr int kGkCounters = 1024;
+static int g_gk = -1;          // ADK_GK16: 0 = never, 1 = where it is preferred (default), 2 = wherever it is supported (tests, A/B)
+static int g_gk_min_work = 0;  // ADK_GK16_MIN_WORK: tiles * chunks from which the kernel is preferred
+
+bool conv_gk16_supported(const ConvArgs& a) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!a.in_sh || !a.wfrag || !al16(a.in_sh) || !al16(a.wfrag) || !al16(a.out)) return false;
+    if (a.cin_g % 64 || a.cout_g % 128 || a.cout_real % 4 || a.n_total < 1 || a.n_total >= (1 << 24)) return false;
+    if (a.in_ch % 8 || a.in_choff % 8 || a.in_gstride % 8 || a.out_ch % 4 || a.out_choff % 4) return false;       // whole 8-channel shadow groups
+    if ((unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull >= 0x80000000ull) return false;
+    if (a.bias && !al16(a.bias)) return false;
+    if (a.res && (a.res_ch % 4 || a.res_choff % 4 || a.res_gstride % 4 || !al16(a.res))) return false;
+    const long long tiles = (long long)(a.cout_g / 128) * ((a.n_total + 127) / 128) * a.groups;
+    return tiles <= kGkCounters;
+}
+
+static void gk_read_env() {
+    if (g_gk < 0) {
+        const char* e = getenv("ADK_GK16"); g_gk = e ? atoi(e) : 1;
+        e = getenv("ADK_GK16_MIN_WORK"); g_gk_min_work = e ? atoi(e) : 1536;
+    }
+}
+void conv_gk16_mode(int mode) { gk_read_env(); g_gk = mode < 0 ? 0 : mode; }      // adk_set_option("gk16", ...)
+
+bool conv_gk16_preferred(const ConvArgs& a) {
+    gk_read_env();
+    if (!g_gk || !conv_gk16_supported(a)) return false;
+    if (g_gk >= 2) return true;
+    // enough work for ~240 workgroups of >= 6 chunks: the wide grouped convs of a v1 vocoder's first stage at >= 128 streams
+    // (60 tiles x 44 chunks at 256); the smaller stream-K launches (a few tiles, K <= 1792) stay where they are
+    const long long tiles = (long long)(a.cout_g / 128) * ((a.n_total + 127) / 128) * a.groups;
+    return tiles * (a.ktot / 64) >= g_gk_min_work;
+}
+
+int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
+    if (a.n_total == 0) return ADK_OK;
+    if (!conv_gk16_supported(a)) return fail(ADK_ERR_STATE, "conv_gk16: unsupported arguments");
+    GkArgs gk;
+    gk.m_tiles = a.cout_g / 128;
+    gk.n_tiles = (a.n_total + 127) / 128;
+    gk.nchunks = a.ktot / 64;
+    gk.cpt = a.cin_g / 64;
+    gk.kgroups = gk.nchunks * 8;
+    gk.mt32_per_g = a.cout_g / 32;
+    gk.inv_t_out = 1.0f / (float)a.t_out;
+    const int tiles = gk.m_tiles * gk.n_tiles * a.groups;
+    int S = 256 / tiles;                                  // one workgroup per CU
+    if (S > 8) S = 8;
+    if (S > gk.nchunks / 2) S = gk.nchunks / 2;           // >= 2 chunks per part
+    if (S < 1) S = 1;
+    gk.S = S; gk.G = tiles * S;
+    size_t flags_offset = 0;
+    const size_t need = conv_mfma_workspace_bytes(&flags_offset);
+    if (!ws.ptr || ws.bytes < need || (size_t)gk.G * 65536 > flags_offset) return fail(ADK_ERR_STATE, "conv_gk16: workspace missing or too small");
+    gk.ws = ws.ptr; gk.ws_bytes = (unsigned)std::min<size_t>(flags_offset, 0x7fffffffu);
+    gk.counters = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws.ptr) + need - kGkCounters * sizeof(unsigned));
+    gk.err = conv_err_word(a);
+    constexpr size_t lds = 4 * GK_BUF + 16;
+    static bool attr_dev[kMaxDevices] = {};
+    bool& attr = attr_dev[current_device()];
+    if (!attr) {
+        ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gk16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    ConvArgs b = a;
+    b.in = a.in_sh;
+    const unsigned grid = (unsigned)((gk.G + 7) / 8 * 8);
+    hipLaunchKernelGGL(conv_gk16_kernel, dim3(grid), dim3(256), lds, s, b, gk);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (a.n_total == 0) return ADK_OK;
     (void)conv_mfma_workspace_bytes(nullptr);
+    if (conv_gk16_preferred(a)) return launch_conv_gk16(a, s, ws);
     // ADK_SK16_KD=2: 128-deep chunks.  Measured: single launches of the small layers 20-30 % faster (transposed convs
     // 26.6 -> 18.8 us), single-stream latency 1.09 -> 1.03 ms, but 67.6 KB of LDS per workgroup keeps concurrently
     // running programs off the CU: 3-stream pipeline 196 k vs 204 k frames/s.  Default 64-deep.

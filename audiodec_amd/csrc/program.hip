@@ -138,6 +138,7 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
+        if (conv_gk16_preferred(a)) return "conv_gk16<128x128>";
         return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
     }
     const bool mf = impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (impl == ADK_IMPL_MFMA || impl == ADK_IMPL_MFMA_ROWS || a.groups * a.cout_g >= 32);
@@ -160,6 +161,7 @@ extern "C" int adk_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_blocks")) { g_chain_min_blocks = value < 0 ? 0 : value; return ADK_OK; }
+    if (!strcmp(name, "gk16")) { conv_gk16_mode(value); return ADK_OK; }
     return fail(ADK_ERR_ARG, std::string("adk_set_option: unknown option ") + name);
 }
 
@@ -663,6 +665,8 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         ConvArgs a;
         int rc = build_args(d, in, out, res, p->batch, frames * o.rate_out, a);
         if (rc != ADK_OK) return rc;
+        if (o.in_shadow > 0) a.in_sh = view_of(p, o.in_shadow - 1, frames, ext, 0).base;      // (kernel choice looks at the shadows)
+        if (o.out_shadow > 0) a.out_sh = view_of(p, o.out_shadow - 1, frames, ext, 0).base;
         name = conv_kernel_name(a, o.impl);
         ConvArgs f1, f2;
         ConvArgs c[kMaxChain]; int keep[kMaxChain];

@@ -214,6 +214,8 @@ def _rocprof_name(dom):
         return ("conv_up16_kernel<",)
     if dom.startswith("conv_ou16<"):
         return ("conv_ou16_kernel<",)
+    if dom.startswith("conv_gk16<"):
+        return ("conv_gk16_kernel",)
     return None
 
 
