@@ -723,16 +723,26 @@ struct GkArgs {
     int mt32_per_g;
     float inv_t_out;
     int* err;
+    int dbg;              // ADK_GK16_DBG (tuning; results are garbage): 1 = no B copies after the prologue, 2 = no A copies, 4 = no MFMAs, 8 = no K-part reduction
 };
 
 constexpr int GK_BUF = 32 * 1024;                       // one operand, one chunk
+// ADK_GK16_DBG & 16: wall-clock stamps (s_memrealtime, 100 MHz) of wave 0 of every workgroup of the LAST conv_gk16 launch:
+// 0 entry, 1 prologue copies issued, 2 first chunk landed (past the first barrier), 3 loop done, 4 slabs published + all parts arrived,
+// 5 own slab reduced + finished (epilogue stores issued), 6 exit
+__device__ unsigned long long g_gk_trace[512 * 8];
+extern "C" int adk_debug_gk_trace(unsigned long long* out, int n) {
+    if (n > 512 * 8) n = 512 * 8;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gk_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#define GK_STAMP(i) do { if ((gk.dbg & 16) && wave == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+                         if (lane == 0 && r < 512) g_gk_trace[r * 8 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 
 #define GK_DMA16(gptr, m0val) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                                                             : "=&s"(m0_keep_) : "v"(gptr), "s"(m0val) : "memory"); } while (0)
 
 __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char gks[];      // [A0 | A1 | B0 | B1], 32 KiB each, + 16 bytes
-    unsigned& last_sh = *reinterpret_cast<unsigned*>(gks + 4 * GK_BUF);       // (no static __shared__ next to a dynamic region of this size: it would shift its base off 16 bytes)
+    extern __shared__ __attribute__((aligned(16))) unsigned char gks[];      // [A0 | A1 | B0 | B1], 32 KiB each (no static __shared__ beside it: that would shift its base off 16 bytes)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -742,6 +752,7 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
     const int per_xcd = (gk.G + 7) >> 3;
     const int r = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if (r >= gk.G) return;
+    GK_STAMP(0);
     const int tile = r / gk.S, part = r - tile * gk.S;
     const int mt = tile % gk.m_tiles;
     const int rest = tile / gk.m_tiles;
@@ -798,6 +809,7 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
 #pragma unroll
     for (int p = 0; p < 8; ++p) { issue_a(c0, 0, p); issue_b(0, p); }
     next_chunk();
+    GK_STAMP(1);
 
     // this lane's fragment addresses (bytes from the start of an operand buffer)
     const unsigned a_off = (unsigned)(wm * 2) * 8192u + lane16;                           // + i * 8192 + (2 * st + half) * 1024
@@ -808,6 +820,7 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
         const int buf = (c - c0) & 1;
         // my pieces of chunk c have landed, and so have everybody's; all waves are done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c == c0) GK_STAMP(2);
         const unsigned char* Ab = gks + buf * GK_BUF + a_off;
         const unsigned char* Bb = gks + 2 * GK_BUF + buf * GK_BUF + b_off;
         const bool more = c + 1 < c1;
@@ -826,7 +839,11 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
                 bl[j] = *reinterpret_cast<const f16x8s*>(Bb + j * 32 * 256 + ls);
             }
             // the next chunk's pieces, four per step, between this step's fragment reads and its MFMAs
-            if (more) { issue_a(c + 1, buf ^ 1, 2 * st); issue_a(c + 1, buf ^ 1, 2 * st + 1); issue_b(buf ^ 1, 2 * st); issue_b(buf ^ 1, 2 * st + 1); }
+            if (more) {
+                if (!(gk.dbg & 2)) { issue_a(c + 1, buf ^ 1, 2 * st); issue_a(c + 1, buf ^ 1, 2 * st + 1); }
+                if (!(gk.dbg & 1)) { issue_b(buf ^ 1, 2 * st); issue_b(buf ^ 1, 2 * st + 1); }
+            }
+            if (gk.dbg & 4) continue;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -842,6 +859,7 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
         }
         next_chunk();
     }
+    GK_STAMP(3);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -849,70 +867,143 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(accx[i][j][e], kSkLoInv, acc[i][j][e]);
 
-    if (gk.S > 1) {
-        // publish this part's sums (write-through), count it in, and leave -- unless it was the last one of its tile
-        const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(gk.ws, 0, gk.ws_bytes, 0x00020000);
-        const unsigned wbase = ((unsigned)r * 256u + (unsigned)tid) * 256u;               // 64 floats per thread
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    u32x4 v;
-                    v.x = __float_as_uint(acc[i][j][4 * e4]); v.y = __float_as_uint(acc[i][j][4 * e4 + 1]);
-                    v.z = __float_as_uint(acc[i][j][4 * e4 + 2]); v.w = __float_as_uint(acc[i][j][4 * e4 + 3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)((i * 2 + j) * 64 + e4 * 16), 0, 16 /* sc1 */);
-                }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) last_sh = __hip_atomic_fetch_add(gk.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (last_sh != (unsigned)(gk.S - 1)) return;
-        // last arriver: every part (this one's from its registers) in part order
-        f32x16 tot[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tot[i][j][e] = 0.f;
-        for (int sp = 0; sp < gk.S; ++sp) {
-            if (sp == part) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) tot[i][j][e] += acc[i][j][e];
-            } else {
-                const unsigned rbase = ((unsigned)(tile * gk.S + sp) * 256u + (unsigned)tid) * 256u;
-                u32x4 pv[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, rbase + (unsigned)(q * 16), 0, 16 /* sc1 */);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int e4 = 0; e4 < 4; ++e4) {
-                            const u32x4 v = pv[(i * 2 + j) * 4 + e4];
-                            tot[i][j][4 * e4] += __uint_as_float(v.x); tot[i][j][4 * e4 + 1] += __uint_as_float(v.y);
-                            tot[i][j][4 * e4 + 2] += __uint_as_float(v.z); tot[i][j][4 * e4 + 3] += __uint_as_float(v.w);
-                        }
-            }
-        }
-        if (tid == 0) __hip_atomic_store(gk.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = tot[i][j][e];
-    }
+    // ---- tail.  The tile goes through LDS (the operand buffers are free now) as T[column][128 channels], 528-byte rows: from there
+    // every global access of the tail is a full, coalesced 16 bytes per lane along the channel axis (the accumulator layout has a lane's
+    // neighbours 32 columns = 32 ring rows apart).  With S > 1 the parts of a tile exchange through the workspace, reduce-scatter:
+    // part q finishes the columns [q * 128 / S, (q + 1) * 128 / S) -- it publishes the other parts' column slabs (write-through), counts
+    // itself in, waits until all S parts have (they were dispatched back to back and run in step: they arrive within ~1 us of each
+    // other; the wait is bounded, device flag bit 1), adds the S contributions to ITS slab in part order -- a fixed order, whoever
+    // arrives when -- and runs the epilogue on it.  The last part to have read puts the tile's two counters back to 0. ----
+    constexpr int TS = 528;
+    __syncthreads();                                        // every wave is done with the operand buffers
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        sk_epilogue<2, true>(a, acc[i], g, (mt * 4 + wm * 2 + i) * 32, nt * 128 + wn * 64, lane, gk.err);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            unsigned char* trow = gks + (size_t)(wn * 64 + j * 32 + l31) * TS + (size_t)(wm * 64 + i * 32 + 4 * lh) * 4;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                *reinterpret_cast<float4*>(trow + qd * 32) = make_float4(acc[i][j][4 * qd], acc[i][j][4 * qd + 1], acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3]);
+        }
+    __syncthreads();
+    const int S = (gk.dbg & 8) ? 1 : gk.S;
+    const int W = 128 / S;                                  // columns of this part's slab (S is a power of two <= 8)
+    const int my0 = (gk.dbg & 8) ? 0 : part * W;
+    const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(gk.ws, 0, gk.ws_bytes, 0x00020000);
+    const unsigned slab_bytes = (unsigned)W * 512u;
+    if (S > 1) {
+        // my contribution to the OTHER parts' slabs: 8 columns (4 KiB) per pass, a wave = two whole 512-byte columns per store
+        for (int q = 0; q < S; ++q) {
+            if (q == part) continue;
+            const unsigned dst = ((unsigned)((tile * S + q) * S + part)) * slab_bytes;
+            for (int c = tid >> 5; c < W; c += 8) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(gks + (size_t)(q * W + c) * TS + (size_t)(tid & 31) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, dst + (unsigned)c * 512u + (unsigned)(tid & 31) * 16u, 0, 16 /* sc1 */);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(gk.counters + 2 * tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(gk.counters + 2 * tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)S) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 20)) { atomicOr(gk.err, 2); break; }              // never hang the device
+            }
+        }
+        __syncthreads();
+        GK_STAMP(4);
+    }
+    // ---- my slab: 16 columns per pass, a thread = 8 channels (one shadow group) of one column ----
+    const int cg = tid & 15;
+    const int ml = mt * 128 + 8 * cg;                       // channel within the group
+    const int mg = g * a.cout_g + ml;
+    float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
+    if (a.bias) { bias0 = *reinterpret_cast<const float4*>(a.bias + mg); bias1 = *reinterpret_cast<const float4*>(a.bias + mg + 4); }
+    int ph = 0, ocol = mg;
+    if (a.up > 1) { ph = mg / a.cout_real; ocol = mg - ph * a.cout_real; }
+    bool bad = false;
+    for (int c = tid >> 4; c < W; c += 16) {
+        const int n = nt * 128 + my0 + c;
+        float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+        u32x4 pv[2 * 8];
+        if (S > 1) {
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp)
+                if (sp < S && sp != part) {
+                    const unsigned src = ((unsigned)((tile * S + part) * S + sp)) * slab_bytes + (unsigned)c * 512u + (unsigned)cg * 32u;
+                    pv[2 * sp] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, src, 0, 16 /* sc1 */);
+                    pv[2 * sp + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, src + 16u, 0, 16 /* sc1 */);
+                }
+        }
+        const float4 own0 = *reinterpret_cast<const float4*>(gks + (size_t)(my0 + c) * TS + (size_t)cg * 32);
+        const float4 own1 = *reinterpret_cast<const float4*>(gks + (size_t)(my0 + c) * TS + (size_t)cg * 32 + 16);
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp)
+            if (sp < S) {
+                if (sp == part || S == 1) {
+                    t0.x += own0.x; t0.y += own0.y; t0.z += own0.z; t0.w += own0.w;
+                    t1.x += own1.x; t1.y += own1.y; t1.z += own1.z; t1.w += own1.w;
+                } else {
+                    const u32x4 u = pv[2 * sp], v = pv[2 * sp + 1];
+                    t0.x += __uint_as_float(u.x); t0.y += __uint_as_float(u.y); t0.z += __uint_as_float(u.z); t0.w += __uint_as_float(u.w);
+                    t1.x += __uint_as_float(v.x); t1.y += __uint_as_float(v.y); t1.z += __uint_as_float(v.z); t1.w += __uint_as_float(v.w);
+                }
+            }
+        if (n >= a.n_total) continue;
+        // the stream-K kernel's epilogue (sk_epilogue), 8 channels of one column at a time: bias, residual, output activation, store, shadow
+        bad |= !(fabsf(t0.x) <= 3.0e38f) | !(fabsf(t0.y) <= 3.0e38f) | !(fabsf(t0.z) <= 3.0e38f) | !(fabsf(t0.w) <= 3.0e38f) |
+               !(fabsf(t1.x) <= 3.0e38f) | !(fabsf(t1.y) <= 3.0e38f) | !(fabsf(t1.z) <= 3.0e38f) | !(fabsf(t1.w) <= 3.0e38f);
+        const int bb = fast_div(n, a.t_out, gk.inv_t_out), t = n - bb * a.t_out;
+        if (a.bias) {
+            t0.x += bias0.x; t0.y += bias0.y; t0.z += bias0.z; t0.w += bias0.w;
+            t1.x += bias1.x; t1.y += bias1.y; t1.z += bias1.z; t1.w += bias1.w;
+        }
+        if (a.res) {
+            int rrow = a.res_cursor + t;
+            if (rrow >= a.res_rows) rrow -= a.res_rows;
+            const float* resp = a.res + ((size_t)bb * a.res_rows + rrow) * a.res_ch + a.res_choff + g * a.res_gstride + ml;
+            const float4 r0 = *reinterpret_cast<const float4*>(resp), r1 = *reinterpret_cast<const float4*>(resp + 4);
+            t0.x += r0.x; t0.y += r0.y; t0.z += r0.z; t0.w += r0.w;
+            t1.x += r1.x; t1.y += r1.y; t1.z += r1.z; t1.w += r1.w;
+        }
+        float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        if (a.act_out != ADK_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = act_apply(x[e], a.act_out, 0.f);
+        }
+        int orow = a.out_cursor + t * a.up + ph;
+        if (orow >= a.out_rows) orow -= a.out_rows;
+        const size_t oidx = ((size_t)bb * a.out_rows + orow) * a.out_ch + a.out_choff + ocol;
+        *reinterpret_cast<float4*>(a.out + oidx) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(a.out + oidx + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        if (a.out_sh) {
+            f16x8s hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = act_apply(x[e], a.sh_act, a.sh_slope);
+                const _Float16 h = (_Float16)y;
+                hi[e] = h;
+                lo[e] = (_Float16)((y - (float)h) * kSkLoScale);
+            }
+            unsigned char* sp_ = reinterpret_cast<unsigned char*>(a.out_sh + ((size_t)bb * a.out_rows + orow) * a.out_ch + a.out_choff) + (size_t)(ocol >> 3) * 32;
+            *reinterpret_cast<f16x8s*>(sp_) = hi;
+            *reinterpret_cast<f16x8s*>(sp_ + 16) = lo;
+        }
+    }
+    if (bad) atomicOr(gk.err, 8);
+    if (S > 1) {
+        GK_STAMP(5);
+        __syncthreads();                                    // every thread of this part has read the other parts' slabs
+        if (tid == 0) {
+            const unsigned gone = __hip_atomic_fetch_add(gk.counters + 2 * tile + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone == (unsigned)(S - 1)) {                // the last part to leave: all S are past their waits and their reads
+                __hip_atomic_store(gk.counters + 2 * tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gk.counters + 2 * tile + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    GK_STAMP(6);
 }
 
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
@@ -1175,7 +1266,7 @@ bool conv_gk16_supported(const ConvArgs& a) {
     if (a.bias && !al16(a.bias)) return false;
     if (a.res && (a.res_ch % 4 || a.res_choff % 4 || a.res_gstride % 4 || !al16(a.res))) return false;
     const long long tiles = (long long)(a.cout_g / 128) * ((a.n_total + 127) / 128) * a.groups;
-    return tiles <= kGkCounters;
+    return 2 * tiles <= kGkCounters;          // two counters per tile (arrived / left)
 }
 
 static void gk_read_env() {
@@ -1208,10 +1299,8 @@ int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     gk.mt32_per_g = a.cout_g / 32;
     gk.inv_t_out = 1.0f / (float)a.t_out;
     const int tiles = gk.m_tiles * gk.n_tiles * a.groups;
-    int S = 256 / tiles;                                  // one workgroup per CU
-    if (S > 8) S = 8;
-    if (S > gk.nchunks / 2) S = gk.nchunks / 2;           // >= 2 chunks per part
-    if (S < 1) S = 1;
+    int S = 1;                                            // K parts per tile: a power of two <= 8, one workgroup per CU, >= 2 chunks per part
+    while (S < 8 && tiles * S * 2 <= 256 && gk.nchunks / (S * 2) >= 2) S *= 2;
     gk.S = S; gk.G = tiles * S;
     size_t flags_offset = 0;
     const size_t need = conv_mfma_workspace_bytes(&flags_offset);
@@ -1219,6 +1308,9 @@ int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     gk.ws = ws.ptr; gk.ws_bytes = (unsigned)std::min<size_t>(flags_offset, 0x7fffffffu);
     gk.counters = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws.ptr) + need - kGkCounters * sizeof(unsigned));
     gk.err = conv_err_word(a);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("ADK_GK16_DBG"); dbg = e ? atoi(e) : 0; }
+    gk.dbg = dbg;
     constexpr size_t lds = 4 * GK_BUF + 16;
     static bool attr_dev[kMaxDevices] = {};
     bool& attr = attr_dev[current_device()];
