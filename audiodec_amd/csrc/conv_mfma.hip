@@ -583,7 +583,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
                 // Head of this range: the tile started in an earlier range, whose workgroup owns it.
                 // Publish the raw partial accumulators: write-through (sc1) stores, drain, one flag.
                 const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(sk.ws, 0, sk.ws_bytes, 0x00020000);
-                const unsigned wbase = ((unsigned)r * (unsigned)NT + (unsigned)tid) * (unsigned)(NJ * 64);
+                // layout [range][16-byte piece q][thread]: a wave's store of one piece is 1 KiB contiguous (with the thread-major layout of
+                // rounds 1-3 its 64 lanes were 64 * NJ bytes apart: four times the cache lines per store, and per load on the owner's side)
+                const unsigned wbase = (unsigned)r * (unsigned)(NT * NJ * 64) + (unsigned)tid * 16u;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
                         u32x4 v;
                         v.x = __float_as_uint(acc[j][4 * e4]); v.y = __float_as_uint(acc[j][4 * e4 + 1]);
                         v.z = __float_as_uint(acc[j][4 * e4 + 2]); v.w = __float_as_uint(acc[j][4 * e4 + 3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)(j * 64 + e4 * 16), 0, 16 /* sc1 */);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, wbase + (unsigned)((j * 4 + e4) * (NT * 16)), 0, 16 /* sc1 */);
                     }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains
                 __syncthreads();
@@ -627,10 +629,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
                     for (int rr = r + 1; rr < rr_end; ++rr) {
                         if (sk_u0(rr + 1, sk) <= sk_u0(rr, sk)) continue;
 #if ADK_SK_SC1_READ
-                        const unsigned rbase = ((unsigned)rr * (unsigned)NT + (unsigned)tid) * (unsigned)(NJ * 64);
+                        const unsigned rbase = (unsigned)rr * (unsigned)(NT * NJ * 64) + (unsigned)tid * 16u;
                         u32x4 pv[NJ * 4];
 #pragma unroll
-                        for (int q = 0; q < NJ * 4; ++q) pv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rd, rbase + (unsigned)(q * 16), 0, 16 /* sc1 */);
+                        for (int q = 0; q < NJ * 4; ++q) pv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_rd, rbase + (unsigned)(q * (NT * 16)), 0, 16 /* sc1 */);
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -640,12 +642,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
                                 acc[j][4 * e4 + 2] += __uint_as_float(v.z); acc[j][4 * e4 + 3] += __uint_as_float(v.w);
                             }
 #else
-                        const float* wsp = sk.ws + ((size_t)rr * NT + tid) * (NJ * 16);
+                        const float* wsp = sk.ws + (size_t)rr * NT * (NJ * 16) + (size_t)tid * 4;
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
 #pragma unroll
                             for (int e4 = 0; e4 < 4; ++e4) {
-                                const float4 v = *reinterpret_cast<const float4*>(wsp + j * 16 + 4 * e4);
+                                const float4 v = *reinterpret_cast<const float4*>(wsp + (size_t)(j * 4 + e4) * (NT * 4));
                                 acc[j][4 * e4] += v.x; acc[j][4 * e4 + 1] += v.y; acc[j][4 * e4 + 2] += v.z; acc[j][4 * e4 + 3] += v.w;
                             }
 #endif
@@ -726,7 +728,7 @@ struct GkArgs {
     int dbg;              // ADK_GK16_DBG (tuning; results are garbage): 1 = no B copies after the prologue, 2 = no A copies, 4 = no MFMAs, 8 = no K-part reduction
 };
 
-constexpr int GK_BUF = 32 * 1024;                       // one operand, one chunk
+constexpr int GK_BUF = 32 * 1024;                       // 4 * GK_BUF = the dynamic LDS of the kernel: four stage buffers of 16 + 16 KiB; the tail's tile image after the loop
 // ADK_GK16_DBG & 16: wall-clock stamps (s_memrealtime, 100 MHz) of wave 0 of every workgroup of the LAST conv_gk16 launch:
 // 0 entry, 1 prologue copies issued, 2 first chunk landed (past the first barrier), 3 loop done, 4 slabs published + all parts arrived,
 // 5 own slab reduced + finished (epilogue stores issued), 6 exit
@@ -735,16 +737,21 @@ extern "C" int adk_debug_gk_trace(unsigned long long* out, int n) {
     if (n > 512 * 8) n = 512 * 8;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gk_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
-#define GK_STAMP(i) do { if ((gk.dbg & 16) && wave == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+#define GK_STAMP(i) do { if ((gk.dbg & 16) && wave8 == 0) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
                          if (lane == 0 && r < 512) g_gk_trace[r * 8 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 
 #define GK_DMA16(gptr, m0val) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                                                             : "=&s"(m0_keep_) : "v"(gptr), "s"(m0val) : "memory"); } while (0)
 
-__global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk) {
+__global__ __launch_bounds__(512, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gks[];      // [A0 | A1 | B0 | B1], 32 KiB each (no static __shared__ beside it: that would shift its base off 16 bytes)
+    // 8 waves: waves 0-3 multiply (64 x 64 each) and run the tail, waves 4-7 only copy (LDS-DMA) -- two waves per SIMD, one of each kind.
+    // A wave that did both stalled at the vector-memory issue while its matrix core idled: the copies alone take 10.7 us of the
+    // 128-stream stage-0 conv's loop, the MFMAs + fragment reads alone 12.4 us, one wave doing both 18.2 us (profiles/r4_gk16_timeline.md).
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;                             // multiplier: its quarter of the tile; loader: the quarter of the copies it issues
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -764,38 +771,71 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
     const unsigned lds0 = (unsigned)(size_t)(lds_u8_t)gks;
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    // ---- DMA sources.  A: this wave copies m-tile32 `wave` of the tile: 8 KiB per chunk, contiguous in the packed weights ----
+    // ---- The K range is walked in STAGES of 32 k (two MFMA k-steps): 16 KiB of weight fragments + 16 KiB of shadow rows per stage,
+    // four stage buffers, three stages in flight: a piece has ~2300 MFMA cycles (1.1 us) to land -- what is not in the L2 comes from
+    // the Infinity Cache with a first-touch latency of 1-2 us (profiles/r3_load_rate.md); with 64-k chunks and two buffers (one chunk
+    // ahead) the loop ran at 1.6 us per chunk against 1.0 us without any copies (profiles/r4_gk16_timeline.md).
+    // DMA sources.  A: this wave copies m-tile32 `wave` of the tile: 4 KiB per stage, contiguous in the packed weights ----
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wfrag) +
                                 ((size_t)(g * gk.mt32_per_g + mt * 4 + wave) * gk.kgroups) * 1024u + lane16;
-    // B: piece p of this wave = columns 4 * (8 * wave + p) .. + 3 of the tile, 256 bytes each; lane -> (column, 16-byte slot)
+    // B: piece p of this wave = columns 8 * (4 * wave + p) .. + 7 of the tile, 128 bytes (32 channels: four [8 hi][8 lo] groups) each;
+    // lane -> (column, 16-byte slot), slot ^= (column >> 1) & 7 (two columns share a 256-byte bank row: see the reads below)
     const unsigned row_bytes = (unsigned)a.in_ch * 4u;
     const unsigned ring_bytes = (unsigned)a.in_rows * row_bytes;
     const unsigned dil_bytes = (unsigned)a.dilation * row_bytes;
-    const unsigned char* bsrc[8];          // column base (stream, group, channel offset) + slot of this lane
-    unsigned rowb[8];                      // ring row of tap 0 (bytes)
+    const unsigned char* bsrc[4];          // column base (stream, group, channel offset) + slot of this lane
+    unsigned rowb[4];                      // ring row of tap 0 (bytes)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int col = 4 * (8 * wave + p) + (lane >> 4);
+    for (int p = 0; p < 4; ++p) {
+        const int col = 8 * (4 * wave + p) + (lane >> 3);
         int n = nt * 128 + col;
         if (n >= a.n_total) n = a.n_total - 1;              // (columns past the end: computed on a valid column, never stored)
         const int b = fast_div(n, a.t_out, gk.inv_t_out), t = n - b * a.t_out;
         int row = a.in_row0 + t * a.stride;
         if (row >= a.in_rows) row -= a.in_rows;
         rowb[p] = (unsigned)row * row_bytes;
-        const unsigned slot = (unsigned)((lane & 15) ^ (col & 15));
+        const unsigned slot = (unsigned)((lane & 7) ^ ((col >> 1) & 7));
         bsrc[p] = reinterpret_cast<const unsigned char*>(a.in) + (size_t)b * ring_bytes + (size_t)(a.in_choff + g * a.in_gstride) * 4u + slot * 16u;
     }
-    auto issue_a = [&](int c, int buf, int p) __attribute__((always_inline)) {
-        GK_DMA16(wsrc + (size_t)c * 8192u + (size_t)p * 1024u, lds0 + (unsigned)buf * GK_BUF + (unsigned)wave * 8192u + (unsigned)p * 1024u);
+    constexpr int GK_ST = 16 * 1024;                        // one operand, one stage; buffer q: A at q * 32 KiB, B at q * 32 KiB + 16 KiB
+    const int ns = 2 * (c1 - c0);                           // stages of this part
+    // (tap, 32-channel block) of the stage whose pieces are issued next: wave-uniform
+    int is_ = 0;                                            // ... its index
+    int tap_i = c0 / gk.cpt, hblk_i = 2 * (c0 - tap_i * gk.cpt);
+    const int hpt = 2 * gk.cpt;                             // 32-channel blocks per tap
+    auto issue_stage = [&]() __attribute__((always_inline)) {
+        const unsigned buf = (unsigned)(is_ & 3) * 2u * GK_ST;
+        if (!(gk.dbg & 2)) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                GK_DMA16(wsrc + (size_t)(2 * c0 + is_) * 4096u + (size_t)p * 1024u, lds0 + buf + (unsigned)wave * 4096u + (unsigned)p * 1024u);
+        }
+        if (!(gk.dbg & 1) || is_ < 3) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned rb = rowb[p] + (unsigned)tap_i * dil_bytes;
+                if (rb >= ring_bytes) rb -= ring_bytes;
+                GK_DMA16(bsrc[p] + rb + (unsigned)hblk_i * 128u, lds0 + buf + GK_ST + (unsigned)(4 * wave + p) * 1024u);
+            }
+        }
+        ++is_;
+        if (++hblk_i == hpt) { hblk_i = 0; ++tap_i; }
     };
-    // (tap, 64-channel block) of the chunk whose pieces are being issued: wave-uniform, advanced once per chunk
-    int tap_i = c0 / gk.cpt, cblk_i = c0 - tap_i * gk.cpt;
-    auto issue_b = [&](int buf, int p) __attribute__((always_inline)) {
-        unsigned rb = rowb[p] + (unsigned)tap_i * dil_bytes;
-        if (rb >= ring_bytes) rb -= ring_bytes;
-        GK_DMA16(bsrc[p] + rb + (unsigned)cblk_i * 256u, lds0 + 2u * GK_BUF + (unsigned)buf * GK_BUF + (unsigned)(8 * wave + p) * 1024u);
-    };
-    auto next_chunk = [&]() __attribute__((always_inline)) { if (++cblk_i == gk.cpt) { cblk_i = 0; ++tap_i; } };
+
+    if (loader) {
+        // ---- the copying waves: stages 0 .. 2 up front (a part has >= 4 stages), then one stage per barrier, three ahead ----
+        issue_stage(); issue_stage(); issue_stage();
+        for (int sg = 0; sg < ns; ++sg) {
+            // my pieces of stage sg have landed (8 per stage; those of the <= 2 stages behind it may stay in flight); past the barrier
+            // the multipliers are done reading stage sg - 1, whose buffer the pieces of stage sg + 3 go to
+            const int later = ns - 1 - sg;
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (sg + 3 < ns) issue_stage();
+        }
+        return;                                             // (a wave that has ended is not waited for by the barriers of the tail)
+    }
 
     f32x16 acc[2][2], accx[2][2];
 #pragma unroll
@@ -804,46 +844,34 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; accx[i][j][e] = 0.f; }
-
-    // ---- prologue: chunk c0 into buffer 0 ----
-#pragma unroll
-    for (int p = 0; p < 8; ++p) { issue_a(c0, 0, p); issue_b(0, p); }
-    next_chunk();
     GK_STAMP(1);
 
-    // this lane's fragment addresses (bytes from the start of an operand buffer)
-    const unsigned a_off = (unsigned)(wm * 2) * 8192u + lane16;                           // + i * 8192 + (2 * st + half) * 1024
-    const unsigned x15 = (unsigned)(l31 & 15);
-    const unsigned b_off = (unsigned)(wn * 64 + l31) * 256u;                              // + jn * 32 * 256 + slot * 16
+    // this lane's fragment addresses (bytes from the start of a stage buffer)
+    const unsigned a_off = (unsigned)(wm * 2) * 4096u + lane16;                           // + i * 4096 + (2 * st + half) * 1024
+    const unsigned x8 = (unsigned)((l31 >> 1) & 7);
+    const unsigned b_off = GK_ST + (unsigned)(wn * 64 + l31) * 128u;                      // + jn * 32 * 128 + slot * 16
 
-    for (int c = c0; c < c1; ++c) {
-        const int buf = (c - c0) & 1;
-        // my pieces of chunk c have landed, and so have everybody's; all waves are done reading the other buffer
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c == c0) GK_STAMP(2);
-        const unsigned char* Ab = gks + buf * GK_BUF + a_off;
-        const unsigned char* Bb = gks + 2 * GK_BUF + buf * GK_BUF + b_off;
-        const bool more = c + 1 < c1;
+    for (int sg = 0; sg < ns; ++sg) {
+        // stage sg has landed (the copying waves waited for their pieces before they arrived here); my fragment reads of stage sg - 1
+        // have returned, so its buffer may be overwritten
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (sg == 0) GK_STAMP(2);
+        const unsigned char* Sb = gks + (size_t)(sg & 3) * 2 * GK_ST;
+        if (gk.dbg & 4) continue;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < 2; ++st) {
             f16x8s ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8s*>(Ab + i * 8192 + (2 * st) * 1024);
-                al[i] = *reinterpret_cast<const f16x8s*>(Ab + i * 8192 + (2 * st + 1) * 1024);
+                ah[i] = *reinterpret_cast<const f16x8s*>(Sb + a_off + i * 4096 + (2 * st) * 1024);
+                al[i] = *reinterpret_cast<const f16x8s*>(Sb + a_off + i * 4096 + (2 * st + 1) * 1024);
             }
-            const unsigned hs = ((unsigned)(4 * st + 2 * lh) ^ x15) * 16u, ls = ((unsigned)(4 * st + 2 * lh + 1) ^ x15) * 16u;
+            const unsigned hs = ((unsigned)(4 * st + 2 * lh) ^ x8) * 16u, ls = ((unsigned)(4 * st + 2 * lh + 1) ^ x8) * 16u;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bh[j] = *reinterpret_cast<const f16x8s*>(Bb + j * 32 * 256 + hs);
-                bl[j] = *reinterpret_cast<const f16x8s*>(Bb + j * 32 * 256 + ls);
+                bh[j] = *reinterpret_cast<const f16x8s*>(Sb + b_off + j * 32 * 128 + hs);
+                bl[j] = *reinterpret_cast<const f16x8s*>(Sb + b_off + j * 32 * 128 + ls);
             }
-            // the next chunk's pieces, four per step, between this step's fragment reads and its MFMAs
-            if (more) {
-                if (!(gk.dbg & 2)) { issue_a(c + 1, buf ^ 1, 2 * st); issue_a(c + 1, buf ^ 1, 2 * st + 1); }
-                if (!(gk.dbg & 1)) { issue_b(buf ^ 1, 2 * st); issue_b(buf ^ 1, 2 * st + 1); }
-            }
-            if (gk.dbg & 4) continue;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -857,7 +885,6 @@ __global__ __launch_bounds__(256, 1) void conv_gk16_kernel(ConvArgs a, GkArgs gk
 #pragma unroll
                 for (int j = 0; j < 2; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
         }
-        next_chunk();
     }
     GK_STAMP(3);
 #pragma unroll
@@ -1254,7 +1281,10 @@ int conv_sk16_pick(const ConvArgs& a) {
 
 // ---- conv_gk16 host side ----
 constexpr int kGkCounters = 1024;
-static int g_gk = -1;          // ADK_GK16: 0 = never, 1 = where it is preferred (default), 2 = wherever it is supported (tests, A/B)
+static int g_gk = -1;          // ADK_GK16 / adk_set_option("gk16"): 0 = never (default), 1 = where it is preferred, 2 = wherever it is supported (tests).
+                               // Default off: alone on the chip the kernel takes the wide stage-0 convs from 37.5 to 29.5 us (rocprof: 34.5 vs 41 by events), but a
+                               // workgroup owns its CU (128 KiB of LDS, 8 waves of 256 registers): in the three-stream pipeline, where the other programs'
+                               // workgroups fill the gaps of the stream-K launches, it costs 2.3 % of the throughput (profiles/r4_gk16_timeline.md)
 static int g_gk_min_work = 0;  // ADK_GK16_MIN_WORK: tiles * chunks from which the kernel is preferred
 
 bool conv_gk16_supported(const ConvArgs& a) {
@@ -1271,7 +1301,7 @@ bool conv_gk16_supported(const ConvArgs& a) {
 
 static void gk_read_env() {
     if (g_gk < 0) {
-        const char* e = getenv("ADK_GK16"); g_gk = e ? atoi(e) : 1;
+        const char* e = getenv("ADK_GK16"); g_gk = e ? atoi(e) : 0;
         e = getenv("ADK_GK16_MIN_WORK"); g_gk_min_work = e ? atoi(e) : 1536;
     }
 }
@@ -1311,7 +1341,7 @@ int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("ADK_GK16_DBG"); dbg = e ? atoi(e) : 0; }
     gk.dbg = dbg;
-    constexpr size_t lds = 4 * GK_BUF + 16;
+    constexpr size_t lds = 4 * GK_BUF;
     static bool attr_dev[kMaxDevices] = {};
     bool& attr = attr_dev[current_device()];
     if (!attr) {
@@ -1321,7 +1351,7 @@ int launch_conv_gk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     ConvArgs b = a;
     b.in = a.in_sh;
     const unsigned grid = (unsigned)((gk.G + 7) / 8 * 8);
-    hipLaunchKernelGGL(conv_gk16_kernel, dim3(grid), dim3(256), lds, s, b, gk);
+    hipLaunchKernelGGL(conv_gk16_kernel, dim3(grid), dim3(512), lds, s, b, gk);
     ADK_HIP_CHECK(hipGetLastError());
     return ADK_OK;
 }

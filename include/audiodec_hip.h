@@ -77,8 +77,9 @@ int adk_set_conv_cfg(int32_t cfg);
  *   "chain_min_blocks"    ... and only for launches of at least this many (stream, group) pairs (default 160, the measured
  *                         crossover: below it the per-op launches, which spread a stream's time tiles over many CUs, are faster)
  *   "gk16"                the DMA-fed 128 x 128-tile kernel for convs whose input ring has a shadow (csrc/conv_mfma.hip, conv_gk16):
- *                         0 never (the stream-K kernel takes them), 1 where it is preferred (default: the wide layers with enough
- *                         tiles x K chunks to fill the chip), 2 wherever it is supported (tests).  Results of the two kernels agree to
+*                         0 never (default: the stream-K kernel takes them), 1 where it is preferred (the wide layers with enough
+ *                         tiles x K chunks to fill the chip: faster alone on the chip, slower beside two other programs), 2 wherever it
+ *                         is supported (tests).  Results of the two kernels agree to
  *                         f32 round-off (K is cut elsewhere), each is bit-reproducible.
  * ADK_ERR_ARG for an unknown name. */
 int adk_set_option(const char* name, int32_t value);
