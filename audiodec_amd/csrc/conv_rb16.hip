@@ -53,6 +53,9 @@
 #ifndef ADK_RB16_HIST_LATE
 #define ADK_RB16_HIST_LATE 1
 #endif
+#ifndef ADK_RB16_HIST_LATE128
+#define ADK_RB16_HIST_LATE128 0     // 128-channel variants: the next conv's history rows (up to 64 registers of pieces per thread) requested behind the finish pass
+#endif
 #ifndef ADK_RB16_EARLY64
 #define ADK_RB16_EARLY64 true      // 64-channel ring variant: residual fetched under the second conv's MFMAs (true) or behind them
 #endif
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr bool BIAS_LDS = C < 128 && !(C == 64 && (SMAX == 2 || WR > 0));    // bias of every conv staged in LDS -- unless the LDS is needed to the last KB for a second / third workgroup per CU
     constexpr int RING_BYTES = WR * 4096;
     constexpr bool BIAS_LATE = WR > 0 && !BIAS_LDS;
-    constexpr bool HIST_LATE = (WR > 0 || ADK_RB16_HIST_LATE > 1) && WPS == 3 && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
+    constexpr bool HIST_LATE = (((WR > 0 || ADK_RB16_HIST_LATE > 1) && WPS == 3) || (C == 128 && ADK_RB16_HIST_LATE128)) && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
                                                      // finish / ring-store pass instead of in front of it (16 registers less at the epilogue's peak)   // bias fetched BEHIND the MFMA loop (16 registers per lane would otherwise live through it)
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
@@ -804,11 +807,16 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     r.n_convs = n; r.batch = a0.batch; r.t = a0.t_out; r.groups = a0.groups;
     r.spw = pl.spw; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
     r.slope = a0.slope; r.err = conv_err_word(a0);
-    // L2 warm-up where a conv's weight block is a few loads per lane (32 / 64 channels: the 32-channel vocoder chain 281 -> 200 us,
-    // the encoder chains 10-20 %); the 128-channel chains would spend 22 line touches per lane and conv on it (17 us of prologue,
-    // no gain in the loops: profiles/r3_rb16_timeline.md) -- their waves walk the weights in lockstep instead (LS)
+    // L2 warm-up where a conv's weight block is a few loads per lane (32 / 64 channels) AND the launch is one workgroup per CU or
+    // less (the encoder's chains: 256 workgroups, every round trip exposed -- encoder block 1 64 -> 68 us without it).  A touch is one
+    // dword per 128-byte line, i.e. 64 cache lines per wave instruction: with three workgroups per CU starting at once the ~27 touch
+    // instructions per wave in front of the staging loads cost more than they save -- round 4, after the pinned prefetch and the
+    // weight ring: vocoder stage 2 (768 workgroups) stage-in 16.7 us, chain 168 -> 152 us without the touches, stage 3 139 -> 137.
+    // The 128-channel chains would spend 22 line touches per lane and conv on it (17 us of prologue, no gain in the loops:
+    // profiles/r3_rb16_timeline.md) -- their waves walk the weights in lockstep instead (LS).
+    // ADK_RB16_WARM: 0 never, 1 always, 2 = the round-3 rule (32 / 64 channels, any launch size).
     static const int warm_env = rb_knob("ADK_RB16_WARM", -1);
-    r.warm = warm_env >= 0 ? warm_env : (pl.C <= 64);
+    r.warm = warm_env == 2 ? (pl.C <= 64) : (warm_env >= 0 ? warm_env : (pl.C <= 64 && pl.blocks <= 384));
 #if ADK_RB16_DBG & 1
     r.dbg_slot = g_rb_launch++;
 #endif
