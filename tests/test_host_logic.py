@@ -225,15 +225,17 @@ def test_extra_aliases_are_not_reference_names():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r3_bench_latest.json is one JSON line of bench.py on an MI355X: the keys the driver and the judge read are there, the
-    metric / unit are BASELINE.json's, `value` is consistent with `ms_per_step`, roofline.frac = achieved / peak."""
+    """profiles/r4_bench_latest.json is one JSON line of bench.py on an MI355X: the keys the driver and the judge read are there, the
+    metric / unit are BASELINE.json's, `value` is consistent with `ms_per_step`, roofline.frac = achieved / peak -- and reproducible from
+    the committed rocprofv3 kernel trace of the timed schedule alone."""
+    import csv
     import json
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    line = open(os.path.join(root, "profiles", "r3_bench_latest.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(root, "profiles", "r4_bench_latest.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "cpu_baseline", "guard", "guarded", "frames_per_s_of_each_rank", "distributed"):
         assert k in d, k
     assert d["unit"] == "frames/s" and "frames/s" in base["metric"] and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
@@ -245,11 +247,25 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["self_check"]["ok"] is True and d["device_error_flags"] == 0
-    # round 3: the traffic / rocprof figures name the build they were profiled on, the event overhead is measured and subtracted
-    assert r["traffic_stale"] is False and r["rocprof_stale"] is False and 1.0 < r["event_pair_overhead_us"] < 10.0
-    assert r["avg_launch_us"] < r["avg_launch_us_with_event"] and r["launches_per_step_all_kernels"] <= 45
+    # round 4: frac is the dispatch duration of the dominant kernel in the committed trace of the PIPELINED schedule (the one `value` is timed
+    # in), taken from a trace of the same build; the serial trace and the live event figures stand beside it
+    assert r["frac_schedule"] == "pipelined" and r["traffic_stale"] is False and r["rocprof_stale"] is False and "rocprofv3" in r["frac_source"]
+    assert r["frac"] == r["frac_pipelined"] and r["frac_serial"] > r["frac_pipelined"] > 0.0
+    assert r["frac_events_serial"] > r["frac_events_pipelined"] > 0.0 and 1.0 < r["event_record_us_serial"] < 10.0
+    rows = [q for q in csv.DictReader(l for l in open(os.path.join(root, "profiles", "r4_kernel_stats_steady.csv")) if not l.startswith("#"))
+            if "conv_sk_kernel<2, 2, 1," in q["kernel"] and "true" in q["kernel"]]
+    assert r["kernel"] == "conv_sk16<64x64>" and rows
+    us = sum(float(q["total_us"]) for q in rows) / sum(float(q["launches"]) for q in rows)
+    assert abs(r["flops_per_launch"] / (us * 1e-6) / 1e12 / r["peak"] - r["frac"]) < 0.05 * r["frac"]       # the judge's recipe closes to 5 %
+    assert r["launches_per_step_all_kernels"] <= 45
+    # the mode `value` was timed in, and the facade's default beside it
+    assert d["guard"].startswith("off") and 0 < d["guarded"]["value"] < d["value"] and d["guarded"]["single_stream_ms"] > 0
     ct = d["roofline_convtr"]
     assert ct["bound"] == "hbm" and ct["fused_with_conv_out"] is True and abs(ct["frac"] - ct["achieved"] / ct["peak"]) < 1e-3
+    t5 = d["roofline_convtr_T5"]
+    assert t5["frames_per_step_per_stream"] == 5 and t5["fused_with_conv_out"] is False and 0.2 < t5["transposed_conv_alone"]["frac"] < 1.0
+    for k in ("cfg2_vctk_encoder_rvq_B32", "cfg3_vctk_sym_full_B64"):
+        assert d["extra_configs"][k]["self_check"]["ok"] is True and d["extra_configs"][k]["self_check"]["streams"] in (32, 64)
 
 
 def test_pmc_summary_keeps_only_the_marked_region(tmp_path):

@@ -12,10 +12,15 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "audiodec_amd", "csrc", "conv_rb16.hip")
 HIPCC = "/opt/rocm/bin/hipcc"
-# <C, ACT, TA, TB, NTW, SMAX, WPS, PF, EARLY_RES, LS> of the launches of a 256-stream vctk_v1 step (LeakyReLU K11 blocks, ELU K7+1x1 units)
-IN_USE = {"Li32ELi2ELi11ELi11ELi3ELi1ELi2": "vocoder stage 3 (32 ch, 3 tiles)", "Li64ELi2ELi11ELi11ELi2ELi1ELi3": "vocoder stage 2 (64 ch)",
-          "Li128ELi2ELi11ELi11ELi2ELi2ELi2": "vocoder stage 1 (128 ch)", "Li32ELi1ELi7ELi1ELi3ELi1ELi2": "encoder block 0 (32 ch)",
-          "Li64ELi1ELi7ELi1ELi2ELi1ELi3": "encoder block 1 (64 ch)", "Li128ELi1ELi7ELi1ELi2ELi2ELi2": "encoder block 2 (128 ch)"}
+# <C, ACT, TA, TB, NTW, SMAX, WPS, PF, EARLY_RES, LS, WR> of the launches of a 256-stream vctk_v1 step (LeakyReLU K11 blocks, ELU K7+1x1 units);
+# WR > 0: the round-4 variants with the shared LDS weight ring
+IN_USE = {"Li32ELi2ELi11ELi11ELi3ELi1ELi2ELi2ELb0ELi0ELi0E": "vocoder stage 3 (32 ch, 3 tiles, register weight stream)",
+          "Li64ELi2ELi11ELi11ELi2ELi1ELi3ELi1ELb1ELi0ELi3E": "vocoder stage 2 (64 ch, weight ring)",
+          "Li128ELi2ELi11ELi11ELi2ELi2ELi2ELi3ELb1ELi4ELi0E": "vocoder stage 1 (128 ch)",
+          "Li32ELi1ELi7ELi1ELi3ELi1ELi2ELi2ELb1ELi0ELi0E": "encoder block 0 (32 ch, 3 tiles)",
+          "Li64ELi1ELi7ELi1ELi2ELi1ELi3ELi1ELb1ELi0ELi3E": "encoder block 1 (64 ch, weight ring)",
+          "Li128ELi1ELi7ELi1ELi2ELi2ELi2ELi3ELb1ELi4ELi0E": "encoder block 2 (128 ch)",
+          "Li64ELi2ELi11ELi11ELi2ELi1ELi3ELi2ELb1ELi0ELi0E": "(round 3) vocoder stage 2 without the ring: ADK_RB16_RING=0"}
 
 
 def main():
