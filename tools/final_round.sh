@@ -1,0 +1,16 @@
+#!/bin/bash
+# The round's final capture, one gpurun call:  tools/final_round.sh <tag>
+#  1. rocprofv3 kernel traces (pipelined + serial) and PMC passes of the timed steps (tools/profile_round.sh) -> copied into profiles/ ON THE BOX
+#  2. bench.py (100 steps, all legs): its roofline.frac now comes from the trace of this very build;  3. bench.py in the driver's form (20 / 5)
+#  4. the chain kernel's phase timeline (debug library tools/dbg/rb1, built beforehand: python tools/rb16_trace.py --build 1)
+#  5. the whole GPU suite
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+tag=$1
+bash tools/profile_round.sh $tag
+cp gpurun_out/${tag}_kernel_stats_steady.csv gpurun_out/${tag}_kernel_stats_serial.csv gpurun_out/${tag}_pmc_traffic.csv profiles/
+bash tools/gpu_session.sh $tag bench
+( timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_20_steps.json 2> gpurun_out/${tag}_bench_20_steps.err ); echo "bench20 rc=$?"
+python tools/rb16_trace.py 256 1 2>&1 | grep -v "^Load\|amdgpu.ids" > gpurun_out/${tag}_rb16_trace.log; echo "trace rc=$?"
+python tools/gk_trace.py 256 2>&1 | tail -9 > gpurun_out/${tag}_gk16_trace.log
+bash tools/gpu_session.sh $tag tests

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 os.environ["ADK_GK16_DBG"] = str(16 | (int(sys.argv[2]) if len(sys.argv) > 2 else 0))
 os.environ["ADK_SPLIT16"] = "1"
+os.environ["ADK_GK16"] = "1"                 # (the kernel is opt-in)
 os.environ["ADK_VOCODER_STAGES"] = "1"
 import numpy as np
 import torch
