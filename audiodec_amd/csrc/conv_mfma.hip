@@ -98,6 +98,7 @@ struct SkArgs {
     int* err;                     // device error word (bit 1: a publish flag never arrived; bit 3: split-f16 operand overflow)
     float inv_t_out;
     long long total;      // tiles * nchunks
+    int epi_lds;          // 1: finished tiles go through LDS to memory (sk_epilogue_lds), 0: straight from the accumulators (sk_epilogue)
 };
 
 constexpr int kActPre = 100;   // ACT template value of the stream-K kernel: the staged pieces come from a shadow ring, already activated and split
@@ -218,6 +219,80 @@ __device__ __forceinline__ int fast_div(int n, int d, float inv_d) {
     if (r < 0) { --q; r += d; }
     if (r >= d) { ++q; }
     return q;
+}
+
+// The same epilogue with the tile taken through LDS first (round 4).  In the accumulator layout a lane's neighbours are 32 columns = 32
+// ring rows apart: sk_epilogue writes a 32 x 32 block as 32-byte fragments, one cache line touched per lane pair and store.  Here the
+// workgroup's BM x BN tile is written to T[column][BM channels] (row stride BM + 4 floats: conflict-free float4 writes) and read back
+// with a thread = 8 consecutive channels of one column: every global access (residual, output, shadow) is 16 bytes per lane along the
+// channel axis, a column's BM channels are whole cache lines.  Per element the operations and their order are sk_epilogue's -- the
+// results are bit-identical.  (conv_gk16's tail does the same for its 128 x 128 tile: 19.8 -> 4.4 us, profiles/r4_gk16_timeline.md.)
+// T must hold BN * (BM + 4) floats; the caller brackets the call with the barriers that make the buffer free / keep it until read.
+template <int NJ, int BM, int BN, int NT, bool CHECK>
+__device__ __forceinline__ void sk_epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[NJ], float* T, int g, int m0, int n0, int wm, int wn,
+                                                int tid, float inv_t_out, int* err) {
+    constexpr int TSF = BM + 4;
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float* trow = T + (size_t)(wn * NJ * 32 + j * 32 + l31) * TSF + wm * 32 + 4 * lh;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(trow + 8 * qd) = make_float4(acc[j][4 * qd], acc[j][4 * qd + 1], acc[j][4 * qd + 2], acc[j][4 * qd + 3]);
+    }
+    __syncthreads();
+    constexpr int GPC = BM / 8;                          // 8-channel groups per column
+    bool bad = false;
+    for (int it = tid; it < BN * GPC; it += NT) {
+        const int col = it / GPC, cg = it - col * GPC;
+        const int n = n0 + col;
+        const int ml = m0 + 8 * cg;                      // channel within the group
+        if (n >= a.n_total || ml >= a.cout_g) continue;
+        float4 t0 = *reinterpret_cast<const float4*>(T + (size_t)col * TSF + 8 * cg);
+        float4 t1 = *reinterpret_cast<const float4*>(T + (size_t)col * TSF + 8 * cg + 4);
+        if (CHECK) bad |= !(fabsf(t0.x) <= 3.0e38f) | !(fabsf(t0.y) <= 3.0e38f) | !(fabsf(t0.z) <= 3.0e38f) | !(fabsf(t0.w) <= 3.0e38f) |
+                          !(fabsf(t1.x) <= 3.0e38f) | !(fabsf(t1.y) <= 3.0e38f) | !(fabsf(t1.z) <= 3.0e38f) | !(fabsf(t1.w) <= 3.0e38f);
+        const int b = fast_div(n, a.t_out, inv_t_out), t = n - b * a.t_out;
+        const int mg = g * a.cout_g + ml;
+        if (a.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + mg), b1 = *reinterpret_cast<const float4*>(a.bias + mg + 4);
+            t0.x += b0.x; t0.y += b0.y; t0.z += b0.z; t0.w += b0.w;
+            t1.x += b1.x; t1.y += b1.y; t1.z += b1.z; t1.w += b1.w;
+        }
+        if (a.res) {
+            int rrow = a.res_cursor + t;
+            if (rrow >= a.res_rows) rrow -= a.res_rows;
+            const float* resp = a.res + ((size_t)b * a.res_rows + rrow) * a.res_ch + a.res_choff + g * a.res_gstride + ml;
+            const float4 r0 = *reinterpret_cast<const float4*>(resp), r1 = *reinterpret_cast<const float4*>(resp + 4);
+            t0.x += r0.x; t0.y += r0.y; t0.z += r0.z; t0.w += r0.w;
+            t1.x += r1.x; t1.y += r1.y; t1.z += r1.z; t1.w += r1.w;
+        }
+        float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        if (a.act_out != ADK_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = act_apply(x[e], a.act_out, 0.f);
+        }
+        int orow = a.out_cursor + t * a.up, ocol = mg;
+        if (a.up > 1) { const int ph = mg / a.cout_real; orow += ph; ocol = mg - ph * a.cout_real; }
+        if (orow >= a.out_rows) orow -= a.out_rows;
+        const size_t oidx = ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + ocol;
+        *reinterpret_cast<float4*>(a.out + oidx) = make_float4(x[0], x[1], x[2], x[3]);
+        *reinterpret_cast<float4*>(a.out + oidx + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        if (CHECK && a.out_sh) {
+            f16x8s hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = act_apply(x[e], a.sh_act, a.sh_slope);
+                const _Float16 h = (_Float16)y;
+                hi[e] = h;
+                lo[e] = (_Float16)((y - (float)h) * kSkLoScale);
+            }
+            unsigned char* sp = reinterpret_cast<unsigned char*>(a.out_sh + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff) + (size_t)(ocol >> 3) * 32;
+            *reinterpret_cast<f16x8s*>(sp) = hi;
+            *reinterpret_cast<f16x8s*>(sp + 16) = lo;
+        }
+    }
+    if (CHECK && bad) atomicOr(err, 8);
 }
 
 // Main kernel.  One iteration = one 64-deep K chunk (two 32-channel half-chunks, which may belong to
@@ -653,7 +728,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
 #endif
                     }
                 }
-                sk_epilogue<NJ, SPLIT>(a, acc, cur_g, ml0, n0w, lane, sk.err);
+                if constexpr (WGM <= 2) {
+                    if (sk.epi_lds) {
+                        // buffer `cur` was this iteration's B operand: free once every wave is past its MFMAs; the next iteration
+                        // stores into it again only behind the barrier at the end of this one
+                        __syncthreads();
+                        sk_epilogue_lds<NJ, 32 * WGM, BN, NT, SPLIT>(a, acc, Bs + cur * BN * LDK, cur_g, cur_mt * (32 * WGM), cur_nt * BN, wm, wn, tid, sk.inv_t_out, sk.err);
+                    } else {
+                        sk_epilogue<NJ, SPLIT>(a, acc, cur_g, ml0, n0w, lane, sk.err);
+                    }
+                } else {
+                    sk_epilogue<NJ, SPLIT>(a, acc, cur_g, ml0, n0w, lane, sk.err);
+                }
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -1157,6 +1243,14 @@ int launch_cfg(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     sk.epoch = ++ws.epoch;
     if (sk.epoch == 0) sk.epoch = ++ws.epoch;
     sk.err = conv_err_word(a);
+    {
+        // finished tiles through LDS (coalesced 16-byte accesses along the channel axis) where the tile image fits a staging buffer
+        // (<= 64 rows) and 8-channel groups never straddle a row / a phase of a transposed conv; ADK_SK_EPI_LDS=0: the round-1..3 epilogue
+        static int epi = -1;
+        if (epi < 0) { const char* e = getenv("ADK_SK_EPI_LDS"); epi = e ? atoi(e) : 1; }
+        sk.epi_lds = (epi && WGM <= 2 && a.cout_g % 8 == 0 && a.cout_real % 8 == 0 && a.out_ch % 8 == 0 && a.out_choff % 8 == 0 &&
+                      (!a.res || (a.res_ch % 4 == 0 && a.res_choff % 4 == 0 && a.res_gstride % 4 == 0))) ? 1 : 0;
+    }
     if (lds > 64 * 1024) {
         static bool attr_set_dev[kMaxDevices] = {};      // function attributes are per device
         bool& attr_set = attr_set_dev[current_device()];
