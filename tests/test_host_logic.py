@@ -322,3 +322,54 @@ def test_bench_gpus_n_launches_its_own_ranks_or_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_shadow_ring_assignment_is_shape_only_and_consistent():
+    """Builder.assign_shadows (audiodec_amd/program.py): which rings get a shadow is decided from shapes alone -- the split-f16 lowering
+    and its exact-f32 twin lay out the same arena (HipProgram.demote copies one onto the other) --; in the split lowering every op
+    that writes a shadowed ring carries out_shadow + the readers' activation + ADK_IMPL_SPLIT16_SK, every stream-K reader in_shadow;
+    chains the chain kernel takes (<= 128 channels), fusable pairs, rings written by ring_write / mean ops and offline programs get none."""
+    from audiodec_amd import native, program, synth, configs
+    for model in ("vctk_v1", "vctk_sym", "vctk_v0"):
+        _, enc_tag, _, dec_tag, _ = configs.alias(model)
+        _, _, pe = configs.experiment(enc_tag)
+        mt_d, _, pd = configs.experiment(dec_tag)
+        sde, sdd = synth.synth_state_dict(enc_tag, 1), synth.synth_state_dict(dec_tag, 1)
+        makers = [lambda s16, off=False: program.build_encoder(sde, pe, s16)]
+        if mt_d in ("HiFiGAN", "UnivNet"):
+            makers += [lambda s16, off=False, part=part: program.build_hifigan(sdd, pd, off, s16, part, [2]) for part in (0, 1)]
+        else:
+            makers += [lambda s16, off=False: program.build_sym_decoder(sdd, pd, off, s16)]
+        n_shadow = 0
+        for mk in makers:
+            b, bf = mk(True), mk(False)
+            b.assign_shadows(); bf.assign_shadows(); b.assign_shadows()            # (idempotent)
+            geo = lambda bb: [(r["channels"], r["hist"], r["rate"], r["external"]) for r in bb.rings]
+            assert geo(b) == geo(bf)                                               # same arena layout for the twin
+            assert not any(op.in_shadow or op.out_shadow for op in bf.ops)         # ... which leaves the shadows alone
+            n_shadow += len(b.shadow_of)
+            for rid, sh in b.shadow_of.items():
+                r, s = b.rings[rid], b.rings[sh]
+                assert (s["channels"], s["hist"], s["rate"]) == (r["channels"], r["hist"], r["rate"]) and s["external"] < 0 and r["external"] < 0
+                writers = [op for op in b.ops if op.out_ring == rid]
+                readers = [op for op in b.ops if op.kind == native.OP_CONV and op.in_ring == rid and op.in_shadow]
+                assert writers and readers
+                acts = {(op.conv.act_in, op.conv.act_in_slope) for op in readers}
+                assert len(acts) == 1
+                act, slope = next(iter(acts))
+                for op in writers:
+                    assert op.kind == native.OP_CONV and op.out_shadow == sh + 1 and op.impl == native.IMPL_SPLIT16_SK
+                    assert op.shadow_act == act and abs(op.shadow_slope - slope) < 1e-12 and op.conv.cin_g >= program.SHADOW_MIN_CH
+                    assert op.chain < 2 or op.conv.cin_g > 128                      # never the head of a chain the chain kernel takes
+                for op in readers:
+                    assert op.in_shadow == sh + 1 and op.conv.cin_g >= program.SHADOW_MIN_CH
+            for i, op in enumerate(b.ops):                                          # no shadow reaches into a chain kernel's rings or a fused pair
+                if op.kind == native.OP_CONV and op.conv.cin_g in (32, 64):
+                    assert not op.in_shadow and not op.out_shadow, b.op_names[i]
+        assert n_shadow >= 10, (model, n_shadow)
+    # offline lowering (history replicate in front of the transposed convs): no shadows at all
+    _, _, _, dec_tag, _ = configs.alias("vctk_v1")
+    _, _, pd = configs.experiment(dec_tag)
+    bo = program.build_hifigan(synth.synth_state_dict(dec_tag, 1), pd, True, True)
+    bo.assign_shadows()
+    assert not bo.shadow_of and not any(op.in_shadow or op.out_shadow for op in bo.ops)
