@@ -162,6 +162,11 @@ extern "C" int adk_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_blocks")) { g_chain_min_blocks = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "gk16")) { conv_gk16_mode(value); return ADK_OK; }
+    {
+        const int r = rvq_set_option(name, value);
+        if (r == 0) return ADK_OK;
+        if (r < 0) return fail(ADK_ERR_ARG, std::string("adk_set_option: bad value for ") + name);
+    }
     return fail(ADK_ERR_ARG, std::string("adk_set_option: unknown option ") + name);
 }
 

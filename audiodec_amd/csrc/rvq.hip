@@ -3,6 +3,7 @@
 //   lookup: ResidualVQ.lookup (layers/vq_module.py:159-161)
 //   ring_write: torch.cat of new rows onto the state (layers/conv_layer.py:154) + HiFiGAN decode_norm
 //               (models/vocoder/HiFiGAN.py:276-279)
+#include <cstring>
 #include "adk_common.h"
 #include <cstdlib>
 #include <mutex>
@@ -352,6 +353,132 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v3_kernel(const float*
     if (zq && wave == 0) zq[(size_t)row * D + lane] = qsum;
 }
 
+// ---- v4: v3 with R rows per workgroup sharing the code registers (round 4) ----
+// At 256 rows every CU pulled each stage's 256 KB of codes for ONE row: 64 MB per stage through the L2s, 512 MB per step -- the stage
+// time of v3 (5.3 us) is that delivery (profiles/r3_load_rate.md), and in the three-stream pipeline it is bandwidth the convs need.
+// Here a workgroup keeps R rows: the 64 code registers of a thread serve R dot products (R independent FMA chains, same per-row
+// operations in the same order: indices and zq bit-identical), the R arg-max reductions share the two barriers of a stage (wave r
+// folds the candidates of row r, fetches its winner, updates its residual), and a launch takes 256 / R workgroups.  Round 3 measured
+// the naive form (rows one after the other, barriers per row) at +1.9 us per extra row and stage; batched, an extra row costs the 64
+// FMAs and one DPP reduction per wave.
+// rows per workgroup of the v4 kernel (ADK_RVQ_ROWS / adk_set_option("rvq_rows"): 0 = v3 at every row count, 2, 4, 1 (default) = 2 up
+// to 512 rows and 4 above: one dispatch round of 256 workgroups each) and the row count from which it takes over (ADK_RVQ_V4_MIN /
+// "rvq_v4_min": default 192 -- below, a workgroup per row is a partial round and faster: 26-28 us against 31.6).
+// Measured alone on the chip (tools/rvq_time.py, us per launch of 8 stages; rows/wg 1 = v3 to 256 rows, the first-round kernel above):
+//   rows    1/wg   2/wg   4/wg        in the three-stream pipeline at 256 rows, 2/wg against 1/wg: 282.5 k against 275.7 k frames/s
+//    256    31.1   31.6   42.9        (same box, alternating): half the workgroups, half the code bytes pulled through the L2s
+//    512    78.3   36.5   42.9
+//   1024    79.3   66.3   46.7
+static int g_rvq_rows = -1, g_rvq_v4_min = 192;
+static void rvq_read_env() {
+    if (g_rvq_rows >= 0) return;
+    const char* e = getenv("ADK_RVQ_ROWS");
+    const int v = e ? atoi(e) : 1;
+    g_rvq_rows = (v == 0 || v == 2 || v == 4) ? v : 1;
+    e = getenv("ADK_RVQ_V4_MIN"); if (e) g_rvq_v4_min = atoi(e);
+}
+int rvq_set_option(const char* name, int value) {
+    rvq_read_env();
+    if (!strcmp(name, "rvq_rows")) { if (value != 0 && value != 1 && value != 2 && value != 4) return -1; g_rvq_rows = value; return 0; }
+    if (!strcmp(name, "rvq_v4_min")) { g_rvq_v4_min = value < 1 ? 1 : value; return 0; }
+    return 1;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+// acc.{x,y} = fma(a.{x,y}, e.x, acc.{x,y}) / ... e.y ...: v_pk_fma_f32 with one half of the register pair e as the operand of both
+// lanes (two IEEE FMAs; the compiler of this toolchain only ever selects the low half, i.e. spends a pair per code register).
+__device__ __forceinline__ void pk_fma_lo(f2& acc, f2 a, f2 e) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(e));
+}
+__device__ __forceinline__ void pk_fma_hi(f2& acc, f2 a, f2 e) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(e));
+}
+template <int R>
+__global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v4_kernel(const float* __restrict__ z, const float* __restrict__ embed,
+                                                                    const float* __restrict__ enorm, long long* __restrict__ idx,
+                                                                    float* __restrict__ zq, int n_rows, int n_q) {
+    constexpr int D = 64, SIZE = 1024;
+    __shared__ __attribute__((aligned(16))) float r2_sh[R / 2][2 * D];   // 2*r, rows of a pair interleaved per dimension: broadcast float4 reads
+    __shared__ float rn_sh[R];
+    __shared__ float red_v[R][RVQ_WAVES];
+    __shared__ int red_i[R][RVQ_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0 = blockIdx.x * R;
+    const bool owner = wave < R;                           // wave r owns row row0 + r (a row past the end: computed on row n_rows - 1, never stored)
+    const int my_row = min(row0 + wave, n_rows - 1);
+    float r_reg = 0.f, qsum = 0.f;
+    f2 e[D / 2];                                           // code registers as pairs: the packed FMA selects a half as its broadcast operand
+    {
+        const float* Ec = embed + tid;
+#pragma unroll
+        for (int d = 0; d < D; ++d) e[d >> 1][d & 1] = Ec[(size_t)d * SIZE];
+    }
+    float en = enorm[tid];
+    if (owner) {
+        r_reg = z[(size_t)my_row * D + lane];
+        r2_sh[wave >> 1][2 * lane + (wave & 1)] = 2.f * r_reg;
+        float v = __fmul_rn(r_reg, r_reg);                 // flatten.pow(2).sum(1): the butterfly of v1
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+        if (lane == 0) rn_sh[wave] = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < n_q; ++st) {
+        const bool has_next = st + 1 < n_q;
+        const float* En = embed + (size_t)(has_next ? st + 1 : st) * D * SIZE + tid;
+        f2 acc2[R / 2];
+#pragma unroll
+        for (int p = 0; p < R / 2; ++p) acc2[p] = (f2){0.f, 0.f};
+#pragma unroll
+        for (int d4 = 0; d4 < D / 4; ++d4) {               // (2*flatten) @ embed, d ascending (vq_module.py:95): a row pair per packed FMA
+#pragma unroll
+            for (int p = 0; p < R / 2; ++p) {              // (v_pk_fma_f32: two IEEE FMAs, each row's chain is the chain of v3)
+                const float4 a = *reinterpret_cast<const float4*>(&r2_sh[p][8 * d4]);       // {row 2p, row 2p+1} of d, d+1
+                const float4 b = *reinterpret_cast<const float4*>(&r2_sh[p][8 * d4 + 4]);   // ... of d+2, d+3
+                pk_fma_lo(acc2[p], (f2){a.x, a.y}, e[2 * d4]);
+                pk_fma_hi(acc2[p], (f2){a.z, a.w}, e[2 * d4]);
+                pk_fma_lo(acc2[p], (f2){b.x, b.y}, e[2 * d4 + 1]);
+                pk_fma_hi(acc2[p], (f2){b.z, b.w}, e[2 * d4 + 1]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float a = (r & 1) ? acc2[r / 2].y : acc2[r / 2].x;
+            const float v = -__fadd_rn(__fsub_rn(rn_sh[r], a), en);   // dist = (|r|^2 - 2rE) + |E|^2 ; argmax(-dist), lowest index on ties
+            float vmax;
+            const int best_lane = wave_argmax_lane(v, vmax);
+            if (lane == 0) { red_v[r][wave] = vmax; red_i[r][wave] = (wave << 6) + best_lane; }
+        }
+        __syncthreads();                                   // A: candidates of all waves, all rows
+        float q = 0.f;
+        if (owner) {
+            const float cv = red_v[wave][lane & 15];
+            const float cmax = row_max16(cv);
+            const unsigned long long hit = __ballot(cv == cmax);
+            const int bi = red_i[wave][hit ? __builtin_ctzll(hit) : 0];
+            if (lane == 0 && row0 + wave < n_rows) idx[(size_t)st * n_rows + row0 + wave] = (long long)bi + (long long)SIZE * st;
+            q = embed[((size_t)st * D + lane) * SIZE + bi];         // the winning code of this wave's row: one 64-lane gather, lane = dimension
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) e[d >> 1][d & 1] = En[(size_t)d * SIZE];   // next stage's codes: land under the owners' updates and barrier B
+        en = enorm[(size_t)(has_next ? st + 1 : st) * SIZE + tid];
+        __builtin_amdgcn_sched_barrier(0);
+        if (owner) {                                       // straight-through + residual (vq_module.py:101-102,143-144)
+            const float qp = __fadd_rn(r_reg, __fsub_rn(q, r_reg));
+            r_reg = __fsub_rn(r_reg, qp);
+            qsum = __fadd_rn(qsum, qp);
+            r2_sh[wave >> 1][2 * lane + (wave & 1)] = 2.f * r_reg;
+            float s2 = __fmul_rn(r_reg, r_reg);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s2 = __fadd_rn(s2, __shfl_xor(s2, off, 64));
+            if (lane == 0) rn_sh[wave] = s2;
+        }
+        __syncthreads();                                   // B: residuals of the next stage visible
+    }
+    if (zq && owner && row0 + wave < n_rows) zq[(size_t)(row0 + wave) * D + lane] = qsum;
+}
+
 __global__ __launch_bounds__(256) void rvq_lookup_kernel(const long long* __restrict__ idx, const float* __restrict__ codebook,
                                                          float* __restrict__ zq, int n_rows, int n_q, int dim, int n_codes) {
     const int d4 = dim / 4;
@@ -457,6 +584,16 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
         const char* e = getenv("ADK_RVQ_V1"); variant = (e && atoi(e) == 1) ? 1 : 3;
         e = getenv("ADK_RVQ_V"); if (e && variant != 1 && atoi(e) >= 1 && atoi(e) <= 3) variant = atoi(e);
         e = getenv("ADK_RVQ_MAXROWS"); rb_env = e ? atoi(e) : 0;
+    }
+    rvq_read_env();
+    const int v4_rows = g_rvq_rows == 1 ? (n_rows > 512 ? 4 : 2) : g_rvq_rows, v4_min = g_rvq_v4_min;
+    if (variant == 3 && v4_rows > 0 && dim == 64 && size == 1024 && n_rows >= v4_min) {
+        if (v4_rows == 2)
+            hipLaunchKernelGGL(rvq_encode_v4_kernel<2>, dim3((n_rows + 1) / 2), dim3(RVQ_THREADS), 0, s, z, embed, enorm, reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
+        else
+            hipLaunchKernelGGL(rvq_encode_v4_kernel<4>, dim3((n_rows + 3) / 4), dim3(RVQ_THREADS), 0, s, z, embed, enorm, reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
+        ADK_HIP_CHECK(hipGetLastError());
+        return ADK_OK;
     }
     if (variant >= 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 256)) {
         if (variant == 3) {

@@ -81,6 +81,10 @@ int adk_set_conv_cfg(int32_t cfg);
  *                         tiles x K chunks to fill the chip: faster alone on the chip, slower beside two other programs), 2 wherever it
  *                         is supported (tests).  Results of the two kernels agree to
  *                         f32 round-off (K is cut elsewhere), each is bit-reproducible.
+ *   "rvq_rows"            rows per workgroup of the residual-VQ search when dim == 64, size == 1024 (csrc/rvq.hip, rvq_encode_v4): from
+ *                         "rvq_v4_min" rows (default 192) on, 2 or 4 rows share a workgroup's code registers; 1 (default) = 2 up to 512
+ *                         rows, 4 above; 0: the round-3 kernels at every row count.  Indices and zq are bit-identical either way.
+ *   "rvq_v4_min"          see above
  * ADK_ERR_ARG for an unknown name. */
 int adk_set_option(const char* name, int32_t value);
 /* Introspection of the stream-K launch schedule (pure host logic, no device needed; used by the CPU tests): a matrix-core conv

@@ -391,11 +391,44 @@ def test_rvq_indices_bit_exact_on_reference_latents(gpu, golden_dir):
         explain_flips(idx, g["idx"], g["margin"], name + " (reference z)")
 
 
-@pytest.mark.parametrize("rows", [1, 5, 256, 300])
-def test_rvq_exact_ties_pick_the_lowest_index(gpu, rows):
+@pytest.mark.parametrize("rows,rows_per_wg", [(1, 2), (5, 2), (256, 0), (256, 2), (256, 4), (255, 2), (193, 4), (300, 2), (300, 0), (1021, 4)])
+def test_rvq_exact_ties_pick_the_lowest_index(gpu, rows, rows_per_wg):
     """`(-dist).max(1)` returns the lowest index among equal maxima (vq_module.py:97): duplicate codes inside one wave of the
     search (64 consecutive codes), across waves, and in every stage, with rows sitting exactly on them -- on the one-row-per-
-    workgroup kernel (<= 256 rows: DPP arg-max, owner-only fold) and on the 4-rows kernel (300 rows), against the oracle."""
+    workgroup kernel (< 192 rows, or "rvq_rows" 0 up to 256: DPP arg-max, owner-only fold), on the round-4 kernel with 2 or 4
+    rows per workgroup (packed FMAs, row pairs; odd row counts leave a workgroup half empty) and on the first-round kernel
+    (300 rows with "rvq_rows" 0), against the oracle."""
+    from audiodec_amd import layers, native
+    native.set_option("rvq_rows", rows_per_wg)
+    try:
+        _rvq_ties(gpu, rows)
+    finally:
+        native.set_option("rvq_rows", 1)
+
+
+def test_rvq_row_grouping_is_bit_identical(gpu):
+    """1, 2 or 4 rows per workgroup: the same indices and the same zq, bit for bit (per row the same operations in the same order)."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(777)
+    embeds = [torch.randn(64, 1024, generator=g) * (0.7 ** i) for i in range(8)]
+    rvq = layers.ResidualVQ(embeds, device=gpu)
+    out = {}
+    try:
+        for n in (192, 256, 257, 777):
+            x = torch.randn(1, n, 64, generator=g)
+            for r in (0, 2, 4):
+                native.set_option("rvq_rows", r)
+                q, idx = rvq.forward_index(x, flatten_idx=True)
+                out[r] = (q.cpu(), idx.cpu())
+            for r in (2, 4):
+                assert torch.equal(out[r][1], out[0][1]), (n, r)
+                assert torch.equal(out[r][0], out[0][0]), (n, r, float((out[r][0] - out[0][0]).abs().max()))
+    finally:
+        native.set_option("rvq_rows", 1)
+    assert native.device_flags() == 0
+
+
+def _rvq_ties(gpu, rows):
     from audiodec_amd import layers, native
     g = torch.Generator().manual_seed(4242 + rows)
     embeds = [torch.randn(64, 1024, generator=g) * (0.8 ** i) for i in range(8)]
