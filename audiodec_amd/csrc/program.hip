@@ -89,7 +89,7 @@ static void read_env() {
     if (g_chain_min_c < 0) { const char* e = getenv("ADK_CHAIN_MINC"); g_chain_min_c = e ? atoi(e) : 0; }
     // measured crossover (tools/chain_crossover.py, profiles/r3_chain_crossover.log): below ~160 (stream, group) pairs the per-op launches,
     // which spread one stream's time tiles over many CUs, are faster than one workgroup per pair walking the whole chain
-    if (g_chain_min_blocks < 0) { const char* e = getenv("ADK_CHAIN_MIN_BLOCKS"); g_chain_min_blocks = e ? atoi(e) : 160; }
+    if (g_chain_min_blocks < 0) { const char* e = getenv("ADK_CHAIN_MIN_BLOCKS"); g_chain_min_blocks = e ? atoi(e) : 0; }
 }
 
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {

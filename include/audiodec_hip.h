@@ -74,8 +74,10 @@ int adk_set_conv_cfg(int32_t cfg);
  *                         chain are then launched one by one, as with ADK_CHAIN=0).  State rings are compatible either way:
  *                         the value may change between two steps of a running program.
  *   "chain_min_channels"  ... and from this many channels per group (default 0)
- *   "chain_min_blocks"    ... and only for launches of at least this many (stream, group) pairs (default 160, the measured
- *                         crossover: below it the per-op launches, which spread a stream's time tiles over many CUs, are faster)
+ *   "chain_min_blocks"    ... and only for launches of at least this many (stream, group) pairs (default 0: always.  Until round 4 the
+ *                         default was 160 -- with the chain kernels of that time the per-op launches, which spread a stream's time tiles
+ *                         over many CUs, were faster below it; now the chain is faster at every launch size: 1 stream 0.74 -> 0.71 ms per
+ *                         frame, 48 streams 0.86 -> 0.77 ms, profiles/r4_few_streams.md)
  *   "gk16"                the DMA-fed 128 x 128-tile kernel for convs whose input ring has a shadow (csrc/conv_mfma.hip, conv_gk16):
 *                         0 never (default: the stream-K kernel takes them), 1 where it is preferred (the wide layers with enough
  *                         tiles x K chunks to fill the chip: faster alone on the chip, slower beside two other programs), 2 wherever it

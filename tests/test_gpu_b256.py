@@ -360,7 +360,7 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
     hop = HOP
     old = program.FUSE_RES_UNITS, program.FUSE_CHAINS
     try:
-        native.set_option("chain_min_blocks", 0)             # (by default only launches of >= 160 workgroups run as chains)
+        native.set_option("chain_min_blocks", 0)             # (the default since round 4; launches of <= 128 workgroups run the 8-wave variants)
         native.set_option("chain_max_channels", 64)          # the warm-up of the fused model runs 28 steps: keep it exact too
         program.FUSE_RES_UNITS, program.FUSE_CHAINS = True, True
         ad_f = load_audiodec(ckpt_root, model, 1337, B, max_frames, True)
@@ -416,13 +416,13 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
                     assert float((yf - yu).abs().max()) < 2e-5, (i, float((yf - yu).abs().max()))
     finally:
         native.set_option("chain_max_channels", 128)
-        native.set_option("chain_min_blocks", 160)
+        native.set_option("chain_min_blocks", 0)
     assert native.device_flags() == 0
 
 
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs 2 and 3 at EXACTLY their stream counts (kernel choice is a function of the stream count: few-streams time
-# tiles, chains only from 160 workgroups), through the same checker bench.py's extra_configs runs beside the timing
+# tiles, 8-wave chain kernels up to 128 workgroups), through the same checker bench.py's extra_configs runs beside the timing
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("split16", [True, False], ids=["split16", "f32"])
 @pytest.mark.parametrize("cfg", ["cfg2_encoder_rvq_B32", "cfg3_full_B64"])

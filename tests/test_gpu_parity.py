@@ -339,7 +339,7 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
             assert "noaddl" in model or any(k.startswith("conv_rb16") for k in kinds), kinds     # (x + convs1(act(x)) blocks have no chain)
         z, idx, zq, y = run_hip(ad, audio, chunks)
     finally:
-        native.set_option("chain_min_blocks", 160)
+        native.set_option("chain_min_blocks", 0)
     assert z.shape == g["z"].shape and y.shape == g["y"].shape and idx.shape == g["idx"].shape
     assert np.abs(z - g["z"]).max() < WAVE_TOL
     explain_flips(idx, g["idx"], g["margin"], name)
