@@ -87,6 +87,14 @@ class TxRxPipeline:
         # (round 2) the library default -- up to 512, e.g. exact halves of the 240 tiles of a stage-0 grouped conv -- is as fast
         # and cuts the batch latency (tools/run_r3b.sh: 256 / 384 / 480 / 512 -> 212.3 / 213.5 / 214.2 / 213.0 k frames/s,
         # 1.86 / 1.81 / 1.73 / 1.71 ms), so nothing is set here any more
+        # ADK_BENCH_RVQ (tuning): the HIP stream the residual-VQ search of a batch is launched on -- tx (with the encoder, as the
+        # reference's transmitter thread does; default), rx (with lookup + the first vocoder program), last (with the last vocoder
+        # program), own (a fourth stream).  Measured, two alternating rounds on one box (tools/ab_multi.sh rq ADK_BENCH_RVQ 2 tx rx last own):
+        # tx 285.4 / 285.7 k frames/s, rx 285.2 / 281.6 k, last 244.4 / 243.8 k, own 244.3 / 244.2 k -- the search behind an event on a
+        # stream that is not its producer's or its consumer's costs 14 %
+        where = os.environ.get("ADK_BENCH_RVQ", "tx")
+        self.s_own = [torch.cuda.Stream(dev)] if where == "own" else []
+        self.s_rvq = {"tx": self.s_tx, "rx": self.s_rx, "last": (self.s_more[-1] if self.s_more else self.s_rx), "own": (self.s_own or [None])[0]}[where]
         wg = int(os.environ.get("ADK_BENCH_WORKGROUPS", "0"))
         if wg > 0 and self.two and getattr(ad.decoder, "split16", False):
             ad.tx_encoder.set_workgroups(wg)
@@ -95,10 +103,18 @@ class TxRxPipeline:
     def step(self, x):
         with torch.cuda.stream(self.s_tx):
             z = self.ad.tx_encoder.encode(x)
-            idx = self.ad.tx_encoder.quantize(z)
-            self.last_z, self.last_idx = z, idx            # for the parity checks (tests, --self-check); no extra work
+            if self.s_rvq is self.s_tx:
+                idx = self.ad.tx_encoder.quantize(z)
             ev = torch.cuda.Event()
             ev.record(self.s_tx)
+        if self.s_rvq is not self.s_tx:
+            with torch.cuda.stream(self.s_rvq):
+                self.s_rvq.wait_event(ev)
+                z.record_stream(self.s_rvq)
+                idx = self.ad.tx_encoder.quantize(z)
+                ev = torch.cuda.Event()
+                ev.record(self.s_rvq)
+        self.last_z, self.last_idx = z, idx                # for the parity checks (tests, --self-check); no extra work
         with torch.cuda.stream(self.s_rx):
             self.s_rx.wait_event(ev)
             idx.record_stream(self.s_rx)
@@ -118,7 +134,7 @@ class TxRxPipeline:
         return mid
 
     def _all(self):
-        return [self.s_tx, self.s_rx] + self.s_more
+        return [self.s_tx, self.s_rx] + self.s_more + self.s_own
 
     def enter(self):            # all streams start after whatever ran on the current stream
         cur = torch.cuda.current_stream(self.dev)
