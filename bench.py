@@ -91,7 +91,8 @@ class TxRxPipeline:
         # reference's transmitter thread does; default), rx (with lookup + the first vocoder program), last (with the last vocoder
         # program), own (a fourth stream).  Measured, two alternating rounds on one box (tools/ab_multi.sh rq ADK_BENCH_RVQ 2 tx rx last own):
         # tx 285.4 / 285.7 k frames/s, rx 285.2 / 281.6 k, last 244.4 / 243.8 k, own 244.3 / 244.2 k -- the search behind an event on a
-        # stream that is not its producer's or its consumer's costs 14 %
+        # stream that is not its producer's or its consumer's costs 14 %: a fourth stream shares one of the runtime's 4 hardware queues
+        # (GPU_MAX_HW_QUEUES=8: own 282 k against 284-286 k; profiles/r4_few_streams.md section 5)
         where = os.environ.get("ADK_BENCH_RVQ", "tx")
         self.s_own = [torch.cuda.Stream(dev)] if where == "own" else []
         self.s_rvq = {"tx": self.s_tx, "rx": self.s_rx, "last": (self.s_more[-1] if self.s_more else self.s_rx), "own": (self.s_own or [None])[0]}[where]
