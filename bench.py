@@ -63,6 +63,9 @@ def step(ad, x):
     return ad.decoder.decode(zq)
 
 
+_PIPE_STREAMS = {}
+
+
 class TxRxPipeline:
     """The reference's streamer runs the transmitter (encode+quantize) and the receiver (lookup+decode) in
     two threads joined by a queue (bin/stream.py:212-239).  Same split here on two HIP streams: the codes
@@ -76,12 +79,20 @@ class TxRxPipeline:
         # difference over 20 steps -- but a SECOND pipeline object with a high-priority stream in the same process (the
         # other-precision leg) then ran 12 % slower (111.7 k vs 126.5 k), so the default stays equal priorities
         prio = [int(v) for v in os.environ.get("ADK_BENCH_PRIO", "0,0,0,0").split(",")] + [0, 0, 0, 0]
-        self.s_tx, self.s_rx = torch.cuda.Stream(dev, priority=prio[0]), torch.cuda.Stream(dev, priority=prio[1])
+        # every pipeline object of the process uses the SAME HIP streams (they are never used concurrently): the runtime deals streams over
+        # 4 hardware queues in creation order, so a second object with fresh streams may find two of its three sharing a queue
+        # (profiles/r4_few_streams.md section 5) -- possibly what the slower second leg above was.  Round 4, final build, same box, alternating:
+        # equal priorities 283.6 / 288.7 k, transmitter high 287.7 / 288.4 k: no difference, equal priorities stay
+        self.n_dec = getattr(ad.decoder, "stages", 1)
+        key = (str(dev), tuple(prio[:1 + max(self.n_dec, 1)]))
+        if key not in _PIPE_STREAMS:
+            _PIPE_STREAMS[key] = [torch.cuda.Stream(dev, priority=prio[i]) for i in range(1 + max(self.n_dec, 1))]
+        pool = _PIPE_STREAMS[key]
+        self.s_tx, self.s_rx = pool[0], pool[1]
         # a vocoder lowered in two stages (set_stages) gets a third stream: its second half of batch i runs under the
         # first half of batch i+1 and the encoder of batch i+2
-        self.n_dec = getattr(ad.decoder, "stages", 1)
         self.two = self.n_dec >= 2
-        self.s_more = [torch.cuda.Stream(dev, priority=prio[2 + i]) for i in range(self.n_dec - 1)]
+        self.s_more = pool[2:2 + self.n_dec - 1]
         # ADK_BENCH_WORKGROUPS (tuning): cap on the persistent workgroups of a stream-K launch.  Round 1 ran the three
         # concurrent programs with 256 (half the chip's slots each: 210 k frames/s vs 189 k at 512); with tile-aligned ranges
         # (round 2) the library default -- up to 512, e.g. exact halves of the 240 tiles of a stage-0 grouped conv -- is as fast
