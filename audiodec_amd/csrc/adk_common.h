@@ -30,8 +30,8 @@ struct ConvArgs {
     int batch, t_out, n_total;      // n_total = batch * t_out GEMM columns
     int ktot;                       // taps * cin_g
     int* err = nullptr;             // sticky device flag word the launch reports to: its program's (adk_program_flags), or nullptr = the device-wide word
-    // "Shadow" rings (round 4, split-f16 stream-K kernel only): a second ring of the SAME geometry as `in` / `out` whose every 4-channel
-    // group (16 bytes, where the f32 ring holds 4 floats) holds the split-f16 operand form of act(x): [4 x f16 hi][4 x f16 lo], hi = f16(y),
+    // "Shadow" rings (round 4, split-f16 stream-K kernel only): a second ring of the SAME geometry as `in` / `out` whose every 8-channel
+    // group (32 bytes, where the f32 ring holds 8 floats) holds the split-f16 operand form of act(x): [8 x f16 hi][8 x f16 lo], hi = f16(y),
     // lo = f16((y - hi) * 2048), y = act(x) with the READERS' input activation.  Written once by the producer's epilogue (out_sh), it
     // replaces the activation + split a consumer otherwise redoes for every staged element -- once per tap and per 64-row m-tile
     // (11 x 4 times for the 256-channel grouped K11 convs).  Same values, bit for bit.
@@ -110,6 +110,7 @@ int flag_pool_acquire(int device, int** word);
 void flag_pool_release(int device, int* word);
 int flag_pool_fetch(int device, int* word, hipStream_t s, int* v);
 int flag_pool_fetch_all(int device, int* acc);
+int flag_word_post(int* word, int* host_dev, hipStream_t s);      // 1-thread kernel: *host_dev (a device-mapped pinned host word) = atomicExch(word, 0); nothing waits
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
 // Makes `device` current for the lifetime of the object (programs are bound to the device they were created on,
 // whatever device the calling thread has current); restores the previous one.

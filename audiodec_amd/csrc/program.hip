@@ -269,6 +269,7 @@ struct adk_program {
     bool profiling = false;
     bool fresh = true;              // no step since create / reset (ADK_OP_HIST_REPLICATE runs only then)
     bool fresh_before = true;       // ... as it was before the last step (adk_program_rewind puts it back)
+    bool replaying = false;         // the step in progress was asked for with ADK_STEP_REPLAY
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
     std::vector<float> last_ms;
     // HIP-graph replay of the steady state (adk_program_set_graph): one captured graph per cursor phase
@@ -278,6 +279,10 @@ struct adk_program {
     std::vector<char> seen;         // phase was run eagerly once (kernel attributes, symbol addresses are set up)
     std::vector<hipGraphExec_t> gexec;
     long long replays = 0, captures = 0;
+    // deferred flag checks (adk_program_flags_post / _poll): pinned host words + events of the last ADK_POST_SLOTS posts
+    int* post_host = nullptr; int* post_host_dev = nullptr;
+    hipEvent_t post_ev[ADK_POST_SLOTS] = {};
+    long long post_next = 0;
 };
 
 static int program_fetch_clear(adk_program* p, hipStream_t s, int* v) { return flag_pool_fetch(p->device, p->flags, s, v); }
@@ -308,11 +313,12 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
         const adk_ring_desc& r = rings[i];
         if (r.channels <= 0 || r.hist < 0 || r.rate <= 0) return bail(ADK_ERR_SHAPE, "program_create: bad ring desc");
         if (r.external >= 0) {
-            if (r.hist != 0) return bail(ADK_ERR_SHAPE, "program_create: external rings carry no history");
+            if (r.hist != 0 || r.extra_rows != 0) return bail(ADK_ERR_SHAPE, "program_create: external rings carry no history");
             p->rows[i] = 0;
             if (r.external + 1 > p->n_ext) p->n_ext = r.external + 1;
         } else {
-            const long long rows = (long long)r.hist + (long long)max_frames * r.rate;
+            if (r.extra_rows < 0) return bail(ADK_ERR_SHAPE, "program_create: negative extra_rows");
+            const long long rows = (long long)r.hist + (long long)max_frames * r.rate + (long long)r.extra_rows;
             if (rows > 0x7fffffffLL) return bail(ADK_ERR_SHAPE, "program_create: ring too long");
             p->rows[i] = (int32_t)rows;
             const long long need = r.arena_off + (long long)batch * rows * r.channels;
@@ -343,8 +349,12 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
                 if (sh < 0) continue;
                 if (!ring_ok(sh) || sh == of || rings[sh].external >= 0 || rings[of].external >= 0)
                     return bail(ADK_ERR_ARG, "program_create: a shadow ring must be an arena ring of its own, shadowing an arena ring");
-                if (rings[sh].channels != rings[of].channels || rings[sh].hist != rings[of].hist || rings[sh].rate != rings[of].rate)
+                if (rings[sh].channels != rings[of].channels || rings[sh].hist != rings[of].hist || rings[sh].rate != rings[of].rate ||
+                    rings[sh].extra_rows != rings[of].extra_rows)
                     return bail(ADK_ERR_SHAPE, "program_create: a shadow ring must have the geometry of its ring");
+                // the kernels store [8 x f16 hi][8 x f16 lo] per 8-channel group: half a group at the end of a row would land in the next row
+                if (rings[sh].channels % 8 || (side ? o.out_ch_off : o.in_ch_off) % 8)
+                    return bail(ADK_ERR_SHAPE, "program_create: a shadowed ring needs channels % 8 == 0 and channel offsets % 8 == 0");
                 if (!is_split16(o.impl)) return bail(ADK_ERR_ARG, "program_create: shadow rings are for ADK_IMPL_SPLIT16* ops");
                 if (side && o.impl != ADK_IMPL_SPLIT16_SK) return bail(ADK_ERR_ARG, "program_create: an op that writes a shadow ring needs impl = ADK_IMPL_SPLIT16_SK");
                 if (side && (o.out_ch_off != 0 || o.conv.cout_real != rings[of].channels))
@@ -370,6 +380,20 @@ extern "C" int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const a
             return bail(ADK_ERR_ARG, "program_create: unknown op kind");
         }
     }
+    // shadow consistency across ops: every conv that writes a shadowed ring writes the shadow too, with the activation its readers expect
+    for (int i = 0; i < n_ops; ++i) {
+        const adk_op_desc& rd = ops[i];
+        if (rd.kind != ADK_OP_CONV || rd.in_shadow <= 0) continue;
+        for (int j = 0; j < n_ops; ++j) {
+            const adk_op_desc& wr = ops[j];
+            if (wr.kind == ADK_OP_HIST_REPLICATE) continue;
+            if (wr.out_ring != rd.in_ring) continue;
+            if (wr.kind != ADK_OP_CONV || wr.out_shadow != rd.in_shadow)
+                return bail(ADK_ERR_ARG, "program_create: every op that writes a shadowed ring must be a conv carrying the same out_shadow");
+            if (wr.shadow_act != rd.conv.act_in || (wr.shadow_act == ADK_ACT_LEAKY && wr.shadow_slope != rd.conv.act_in_slope))
+                return bail(ADK_ERR_ARG, "program_create: shadow_act / shadow_slope of a writer differ from the act_in / slope of a reader of the shadow");
+        }
+    }
     {
         int rc = ensure_workspace(p->ws);
         if (rc != ADK_OK) { delete p; return rc; }
@@ -391,6 +415,8 @@ extern "C" void adk_program_destroy(adk_program* p) {
     if (p->ws.ptr) (void)hipFree(p->ws.ptr);
     flag_pool_release(p->device, p->flags);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->post_ev) if (e) (void)hipEventDestroy(e);
+    if (p->post_host) (void)hipHostFree(p->post_host);
     delete p;
 }
 
@@ -471,6 +497,7 @@ static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream
     const adk_op_desc& o = p->ops[i];
     int rc = ADK_OK;
     if (consumed) *consumed = 1;
+    if (o.kind == ADK_OP_RING_WRITE && p->replaying) return ADK_OK;      // ADK_STEP_REPLAY: the rows are still where the rewound step put them
     if (o.kind == ADK_OP_CONV) {
         ConvArgs a, a2;
         if (consumed && o.chain >= 2 && o.chain <= max_consume) {
@@ -586,12 +613,38 @@ extern "C" int adk_program_graph_stats(const adk_program* p, int64_t* replays, i
     return ADK_OK;
 }
 
+static int program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream);
+
 extern "C" int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream) {
     if (!p) return fail(ADK_ERR_ARG, "program_step: null program");
+    p->replaying = false;
+    return program_step(p, frames, ext, n_ext, stream);
+}
+
+extern "C" int adk_program_step_ex(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream, int32_t step_flags) {
+    if (!p) return fail(ADK_ERR_ARG, "program_step_ex: null program");
+    if (step_flags & ~ADK_STEP_REPLAY) return fail(ADK_ERR_ARG, "program_step_ex: unknown step flag");
+    p->replaying = (step_flags & ADK_STEP_REPLAY) != 0;
+    const int rc = program_step(p, frames, ext, n_ext, stream);
+    p->replaying = false;
+    return rc;
+}
+
+static int program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream) {
     if (frames <= 0 || frames > p->max_frames) return fail(ADK_ERR_SHAPE, "program_step: frames must be in [1, max_frames]");
     if (n_ext < p->n_ext || (p->n_ext > 0 && !ext)) return fail(ADK_ERR_ARG, "program_step: missing external buffers");
-    for (int i = 0; i < p->n_ext; ++i)
-        if (!ext[i]) return fail(ADK_ERR_ARG, "program_step: null external buffer");
+    for (int i = 0; i < p->n_ext; ++i) {
+        if (ext[i]) continue;
+        bool needed = !p->replaying;                       // on a replay the sources of the ring writes may be absent
+        for (size_t k = 0; k < p->ops.size() && !needed; ++k) {
+            const adk_op_desc& o = p->ops[k];
+            auto is_ext = [&](int id) { return id >= 0 && p->rings[id].external == i; };
+            if (o.kind == ADK_OP_RING_WRITE) continue;
+            if (o.kind == ADK_OP_MEAN) { for (int q = 0; q < o.n_mean; ++q) needed |= is_ext(o.mean_rings[q]); needed |= is_ext(o.out_ring); }
+            else needed |= is_ext(o.in_ring) || is_ext(o.out_ring) || is_ext(o.res_ring);
+        }
+        if (needed) return fail(ADK_ERR_ARG, "program_step: null external buffer");
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     DeviceGuard guard(p->device);            // launches, the workspace and the flag word belong to the program's device
     const int n_ops = (int)p->ops.size();
@@ -707,6 +760,45 @@ extern "C" int adk_program_flags(adk_program* p, void* stream, int32_t* out) {
     const int rc = program_fetch_clear(p, static_cast<hipStream_t>(stream), &v);
     *out = v;
     return rc;
+}
+
+extern "C" int adk_program_flags_post(adk_program* p, void* stream, int64_t* ticket) {
+    if (!p || !ticket) return fail(ADK_ERR_ARG, "program_flags_post: null argument");
+    DeviceGuard guard(p->device);
+    if (!p->post_host) {
+        int* h = nullptr; int* hd = nullptr;
+        ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), ADK_POST_SLOTS * sizeof(int), hipHostMallocMapped));
+        memset(h, 0, ADK_POST_SLOTS * sizeof(int));
+        ADK_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0));
+        p->post_host = h; p->post_host_dev = hd;
+    }
+    const int slot = (int)(p->post_next % ADK_POST_SLOTS);
+    if (!p->post_ev[slot]) ADK_HIP_CHECK(hipEventCreateWithFlags(&p->post_ev[slot], hipEventDisableTiming));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rc = flag_word_post(p->flags, p->post_host_dev + slot, s);
+    if (rc != ADK_OK) return rc;
+    ADK_HIP_CHECK(hipEventRecord(p->post_ev[slot], s));
+    *ticket = p->post_next++;
+    return ADK_OK;
+}
+
+extern "C" int adk_program_flags_poll(adk_program* p, int64_t ticket, int32_t block, int32_t* done, int32_t* flags) {
+    if (!p || !done || !flags) return fail(ADK_ERR_ARG, "program_flags_poll: null argument");
+    if (ticket < 0 || ticket >= p->post_next || ticket + ADK_POST_SLOTS < p->post_next)
+        return fail(ADK_ERR_STATE, "program_flags_poll: unknown ticket, or more than ADK_POST_SLOTS posts since it was issued");
+    const int slot = (int)(ticket % ADK_POST_SLOTS);
+    DeviceGuard guard(p->device);
+    *done = 0; *flags = 0;
+    if (block) {
+        ADK_HIP_CHECK(hipEventSynchronize(p->post_ev[slot]));
+    } else {
+        const hipError_t e = hipEventQuery(p->post_ev[slot]);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return ADK_OK; }
+        if (e != hipSuccess) return fail(ADK_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    }
+    *done = 1;
+    *flags = reinterpret_cast<volatile int*>(p->post_host)[slot];
+    return ADK_OK;
 }
 
 extern "C" int adk_program_rewind(adk_program* p, int32_t frames) {

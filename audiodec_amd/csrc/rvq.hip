@@ -7,6 +7,7 @@
 #include "adk_common.h"
 #include <cstdlib>
 #include <mutex>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -369,13 +370,17 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v3_kernel(const float*
 //    256    31.1   31.6   42.9        (same box, alternating): half the workgroups, half the code bytes pulled through the L2s
 //    512    78.3   36.5   42.9
 //   1024    79.3   66.3   46.7
-static int g_rvq_rows = -1, g_rvq_v4_min = 192;
+// (atomics: adk_set_option may be called from another host thread than the one that launches; the environment is read exactly once)
+static std::atomic<int> g_rvq_rows{1}, g_rvq_v4_min{192};
+static std::once_flag g_rvq_env_once;
 static void rvq_read_env() {
-    if (g_rvq_rows >= 0) return;
-    const char* e = getenv("ADK_RVQ_ROWS");
-    const int v = e ? atoi(e) : 1;
-    g_rvq_rows = (v == 0 || v == 2 || v == 4) ? v : 1;
-    e = getenv("ADK_RVQ_V4_MIN"); if (e) g_rvq_v4_min = atoi(e);
+    std::call_once(g_rvq_env_once, [] {
+        const char* e = getenv("ADK_RVQ_ROWS");
+        const int v = e ? atoi(e) : 1;
+        g_rvq_rows = (v == 0 || v == 2 || v == 4) ? v : 1;
+        e = getenv("ADK_RVQ_V4_MIN");
+        if (e) { const int m = atoi(e); g_rvq_v4_min = m < 1 ? 1 : m; }        // clamped as rvq_set_option does: 0 rows never reach the v4 grid
+    });
 }
 int rvq_set_option(const char* name, int value) {
     rvq_read_env();
@@ -586,7 +591,8 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
         e = getenv("ADK_RVQ_MAXROWS"); rb_env = e ? atoi(e) : 0;
     }
     rvq_read_env();
-    const int v4_rows = g_rvq_rows == 1 ? (n_rows > 512 ? 4 : 2) : g_rvq_rows, v4_min = g_rvq_v4_min;
+    const int rows_opt = g_rvq_rows.load(), v4_min = g_rvq_v4_min.load();
+    const int v4_rows = rows_opt == 1 ? (n_rows > 512 ? 4 : 2) : rows_opt;
     if (variant == 3 && v4_rows > 0 && dim == 64 && size == 1024 && n_rows >= v4_min) {
         if (v4_rows == 2)
             hipLaunchKernelGGL(rvq_encode_v4_kernel<2>, dim3((n_rows + 1) / 2), dim3(RVQ_THREADS), 0, s, z, embed, enorm, reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
@@ -700,7 +706,14 @@ void flag_pool_release(int device, int* word) {
     if (fp.dev && word > fp.dev && word < fp.dev + kFlagSlots) fp.free_slots.push_back((int)(word - fp.dev));
 }
 
-__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); }
+__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); __threadfence_system(); }
+
+int flag_word_post(int* word, int* host_dev, hipStream_t s) {
+    if (!word || !host_dev) return fail(ADK_ERR_ARG, "flag_word_post: null pointer");
+    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, s, word, host_dev);
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
 
 int flag_pool_fetch(int device, int* word, hipStream_t s, int* v) {
     FlagPool& fp = g_pool[device];

@@ -9,12 +9,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3
 IMPL_AUTO, IMPL_DIRECT, IMPL_MFMA, IMPL_MFMA_ROWS, IMPL_SPLIT16, IMPL_SPLIT16_ROWS, IMPL_SPLIT16_SK, IMPL_SPLIT16_UP = 0, 1, 2, 3, 4, 5, 6, 7
 OP_CONV, OP_RING_WRITE, OP_MEAN, OP_HIST_REPLICATE = 0, 1, 2, 3
+STEP_REPLAY = 1
+POST_SLOTS = 32
 
 
 class RingView(C.Structure):
@@ -33,7 +35,7 @@ class ConvDesc(C.Structure):
 
 class RingDesc(C.Structure):
     _fields_ = [("channels", C.c_int32), ("hist", C.c_int32), ("rate", C.c_int32),
-                ("external", C.c_int32), ("arena_off", C.c_int64)]
+                ("external", C.c_int32), ("arena_off", C.c_int64), ("extra_rows", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class OpDesc(C.Structure):
@@ -73,9 +75,12 @@ SYMBOLS = {
                                      _vp, _i64, C.POINTER(_vp)]),
     "adk_program_destroy": (None, [_vp]),
     "adk_program_step": (C.c_int, [_vp, _i32, C.POINTER(_vp), _i32, _vp]),
+    "adk_program_step_ex": (C.c_int, [_vp, _i32, C.POINTER(_vp), _i32, _vp, _i32]),
     "adk_program_reset": (C.c_int, [_vp, _vp]),
     "adk_program_flags": (C.c_int, [_vp, _vp, C.POINTER(_i32)]),
     "adk_program_rewind": (C.c_int, [_vp, _i32]),
+    "adk_program_flags_post": (C.c_int, [_vp, _vp, C.POINTER(_i64)]),
+    "adk_program_flags_poll": (C.c_int, [_vp, _i64, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "adk_program_get_fresh": (C.c_int, [_vp]),
     "adk_program_set_fresh": (C.c_int, [_vp, _i32]),
     "adk_program_get_cursors": (C.c_int, [_vp, C.POINTER(_i32), _i32]),

@@ -520,26 +520,30 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
 _NICE_PERIODS = (1, 2, 3, 4, 6, 12, 24, 48)
 
 
-def graph_ring_hist(hist, rate, max_frames):
+def graph_ring_hist(hist, rate, max_frames, extra_steps=0):
     """History a ring must keep so that its cursor returns to the same row after a SMALL number of full-size steps: the ring
-    length hist + max_frames*rate becomes a multiple P * (max_frames*rate) with P from _NICE_PERIODS (all divide 48, so the
-    periods of all rings of a program have a small common multiple).  That is what lets adk_program_set_graph capture one
-    launch sequence per cursor phase: ring cursors are kernel arguments."""
+    length hist + (1 + extra_steps) * max_frames * rate becomes a multiple P * (max_frames*rate) with P from _NICE_PERIODS (all
+    divide 48, so the periods of all rings of a program have a small common multiple).  That is what lets adk_program_set_graph
+    capture one launch sequence per cursor phase: ring cursors are kernel arguments.  extra_steps: the rewind_depth rows the ring
+    carries beyond its history and one step (adk_ring_desc.extra_rows)."""
     adv = max_frames * rate
-    need = -(-(hist + adv) // adv)
+    need = -(-(hist + adv) // adv) + extra_steps
     p = next((q for q in _NICE_PERIODS if q >= need), need)
-    return (p - 1) * adv
+    return (p - 1 - extra_steps) * adv
 
 
 class HipProgram:
     """One model half on one HIP device for `batch` streams (C++ adk_program + arena + weights)."""
 
-    def __init__(self, builder, batch, max_frames, device, graph=False, twin=None):
+    def __init__(self, builder, batch, max_frames, device, graph=False, twin=None, rewind_depth=0):
+        """rewind_depth = k: every arena ring gets k * max_frames * rate rows more than its consumers need, so that rewind() can be
+        applied up to k + 1 times in a row -- the history of the step k steps back is still there (deferred guard, pipeline.py)."""
         self.dev = native.require_gpu(device)
         self.lib = native.lib()
         self.batch, self.max_frames = int(batch), int(max_frames)
         self.split16, self.offline = bool(builder.split16), bool(builder.offline)
         self.twin_builder = twin          # () -> Builder of the same lowering with the exact-f32 kernels (demote())
+        self.rewind_depth = 0 if builder.offline else max(0, int(rewind_depth))
         self.graph_requested = bool(graph)
         self.demoted = False
         self.workgroups = 0
@@ -547,7 +551,7 @@ class HipProgram:
         if graph:
             for r in builder.rings:
                 if r["external"] < 0:
-                    r["hist"] = graph_ring_hist(r["hist"], r["rate"], self.max_frames)
+                    r["hist"] = graph_ring_hist(r["hist"], r["rate"], self.max_frames, self.rewind_depth)
         self.op_names = list(builder.op_names)
         self.flops_per_frame = builder.flops_per_frame
         self.n_ops, self.n_rings = len(builder.ops), len(builder.rings)
@@ -555,8 +559,10 @@ class HipProgram:
         self.ring_rows, self.ring_meta = [], []
         rings = (RingDesc * self.n_rings)()
         for i, r in enumerate(builder.rings):
-            rows = r["hist"] + self.max_frames * r["rate"] if r["external"] < 0 else 0
+            extra = self.rewind_depth * self.max_frames * r["rate"] if r["external"] < 0 else 0
+            rows = r["hist"] + self.max_frames * r["rate"] + extra if r["external"] < 0 else 0
             rings[i].channels, rings[i].hist, rings[i].rate, rings[i].external = r["channels"], r["hist"], r["rate"], r["external"]
+            rings[i].extra_rows = extra
             rings[i].arena_off = off if r["external"] < 0 else 0
             self.ring_rows.append(rows)
             self.ring_meta.append(dict(r, rows=rows, arena_off=off))
@@ -564,7 +570,8 @@ class HipProgram:
                 off += self.batch * rows * r["channels"]
                 off += (-off) % 4
         self.arena_floats = max(off, 4)
-        self.state_floats_per_stream = sum(r["hist"] * r["channels"] for r in builder.rings if r["external"] < 0)
+        # (shadow rings are derived state -- the split-f16 form of rows their rings hold -- and are not counted)
+        self.state_floats_per_stream = sum(r["hist"] * r["channels"] for r in builder.rings if r["external"] < 0 and "shadow_of" not in r)
         self.weights = builder.blob.tensor().to(self.dev)
         self.weight_floats = self.weights.numel()
         self.arena = torch.zeros(self.arena_floats, dtype=torch.float32, device=self.dev)
@@ -591,11 +598,30 @@ class HipProgram:
         except Exception:
             pass
 
-    def step(self, frames, ext):
+    def step(self, frames, ext, replay=False):
+        """replay=True (adk_program_step_ex, ADK_STEP_REPLAY): the step is being repeated after rewind(); the ring writes are skipped
+        -- the caller's input rows are still in their rings -- and the entries of `ext` they alone read may be None."""
         for i, t in enumerate(ext):
-            self._ext[i] = t.data_ptr()
-        native.check(self.lib.adk_program_step(self.h, int(frames), self._ext, len(ext), native.current_stream(self.dev)),
-                     "adk_program_step")
+            self._ext[i] = t.data_ptr() if t is not None else None
+        if replay:
+            native.check(self.lib.adk_program_step_ex(self.h, int(frames), self._ext, len(ext), native.current_stream(self.dev), native.STEP_REPLAY),
+                         "adk_program_step_ex")
+        else:
+            native.check(self.lib.adk_program_step(self.h, int(frames), self._ext, len(ext), native.current_stream(self.dev)),
+                         "adk_program_step")
+
+    def post_flags(self):
+        """Deferred check (adk_program_flags_post): behind what was just issued on the current HIP stream, store-and-clear this
+        program's flag word into a pinned host word; nothing waits.  Returns the ticket for poll_flags."""
+        t = C.c_int64(0)
+        native.check(self.lib.adk_program_flags_post(self.h, native.current_stream(self.dev), C.byref(t)), "adk_program_flags_post")
+        return int(t.value)
+
+    def poll_flags(self, ticket, block=False):
+        """(done, flags) of a post: done is False while the post has not completed on the device (block=True waits for it)."""
+        d, f = C.c_int32(0), C.c_int32(0)
+        native.check(self.lib.adk_program_flags_poll(self.h, int(ticket), 1 if block else 0, C.byref(d), C.byref(f)), "adk_program_flags_poll")
+        return bool(d.value), int(f.value)
 
     def reset(self):
         native.check(self.lib.adk_program_reset(self.h, native.current_stream(self.dev)), "adk_program_reset")
@@ -616,7 +642,7 @@ class HipProgram:
         Used when a split-f16 step reports an operand beyond the f16 range: rewind(), demote(), repeat the step."""
         if self.twin_builder is None or not self.split16 or self.demoted:
             raise native.NativeError("this program has no exact-f32 twin to fall back to")
-        twin = HipProgram(self.twin_builder(), self.batch, self.max_frames, self.dev, graph=self.graph_requested)
+        twin = HipProgram(self.twin_builder(), self.batch, self.max_frames, self.dev, graph=self.graph_requested, rewind_depth=self.rewind_depth)
         if twin.arena_floats != self.arena_floats or twin.n_rings != self.n_rings or twin.ring_rows != self.ring_rows:
             raise native.NativeError("the exact-f32 twin has a different state layout")
         twin.arena.copy_(self.arena)
@@ -671,7 +697,10 @@ class HipProgram:
                 out.append(None)
                 continue
             rows = (cur[i] - m["hist"] + torch.arange(m["hist"], device=self.dev)) % m["rows"]
-            out.append(self._ring_view(i)[b, rows].clone())
+            v = self._ring_view(i)
+            if "shadow_of" in m:
+                v = v.view(torch.int32)         # f16 pairs: raw bits, never arithmetic
+            out.append(v[b, rows].clone())
         return out
 
     def restore_stream_state(self, b, state):
@@ -682,8 +711,10 @@ class HipProgram:
                 continue
             rows = (cur[i] - m["hist"] + torch.arange(m["hist"], device=self.dev)) % m["rows"]
             v = self._ring_view(i)
+            if "shadow_of" in m:
+                v = v.view(torch.int32)         # (split(act(0)) = 0 for ELU / LeakyReLU / none: a zeroed shadow matches a zeroed ring)
             if state is None:
-                v[b, rows] = 0.0
+                v[b, rows] = 0
             else:
                 v[b, rows] = state[i]
 

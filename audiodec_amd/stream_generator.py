@@ -61,6 +61,11 @@ class _StreamBase:
         self.split16 = os.environ.get("ADK_SPLIT16", "1") == "1"
         self.guard = os.environ.get("ADK_GUARD", "1") == "1"
         self.graph = os.environ.get("ADK_GRAPH", "0") == "1"
+        # steps a program can be taken back by rewind() beyond the last one: extra ring rows (HipProgram(rewind_depth=...)).  What the
+        # deferred guard of pipeline.StreamingPipeline needs (it finds a failed step one to `depth` steps late); 0 = none
+        self.rewind_depth = int(os.environ.get("ADK_REWIND_DEPTH", "4"))
+        self._defer = None              # a list while a pipeline owns the guard: _step appends (program, frames, ticket) and does not wait
+        self._replay = False            # the next steps repeat rewound ones: programs skip their ring writes (HipProgram.step(replay=True))
         self._warm = {}
 
     # ---- torch.nn.Module surface the reference's loader touches (bin/stream.py:59-61) ----
@@ -81,6 +86,13 @@ class _StreamBase:
             raise ValueError("num_streams and max_frames must be >= 1")
         if (num_streams, max_frames) != (self.num_streams, self.max_frames):
             self.num_streams, self.max_frames = int(num_streams), int(max_frames)
+            self._drop_programs()
+        return self
+
+    def set_rewind_depth(self, depth):
+        """Extra ring rows for `depth` more rewindable steps (see __init__).  Rebuilds the programs: call it before the warm-up."""
+        if int(depth) != self.rewind_depth:
+            self.rewind_depth = max(0, int(depth))
             self._drop_programs()
         return self
 
@@ -133,14 +145,19 @@ class _StreamBase:
         """make_builder(split16) -> program.Builder.  The program is lowered in this object's arithmetic and remembers how to
         lower its exact-f32 twin (HipProgram.demote)."""
         pr = program.HipProgram(make_builder(self.split16), self.num_streams, self.max_frames, self._dev(), graph=self.graph and not self.offline,
-                                twin=(lambda: make_builder(False)) if self.split16 else None)
+                                twin=(lambda: make_builder(False)) if self.split16 else None, rewind_depth=self.rewind_depth)
         if self.workgroups:
             pr.set_workgroups(self.workgroups)
         return pr
 
     def _step(self, prog, frames, ext):
         """One program step; with `guard`, checked and -- for a split-f16 range overflow -- repeated on the exact-f32 twin."""
-        prog.step(frames, ext)
+        if self._defer is not None:
+            # a pipeline owns the guard (pipeline.StreamingPipeline): the check is posted behind the step, nobody waits here
+            prog.step(frames, ext, replay=self._replay)
+            self._defer.append((prog, frames, prog.post_flags()))
+            return
+        prog.step(frames, ext, replay=self._replay)
         if not self.guard:
             return
         fl = prog.flags()
@@ -148,7 +165,7 @@ class _StreamBase:
             import warnings
             prog.rewind(frames)
             prog.demote()
-            prog.step(frames, ext)
+            prog.step(frames, ext, replay=self._replay)
             fl = (fl & ~native.FLAG_F16_OVERFLOW) | prog.flags()
             warnings.warn(f"{type(self).__name__}: an operand left the f16 range (|v| > 65504) in a split-f16 conv; the step was repeated with "
                           "the exact-f32 kernels and this program continues on them", RuntimeWarning, stacklevel=3)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 12
+#define ADK_ABI_VERSION 13
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -225,6 +225,11 @@ typedef struct {
     int32_t rate;        /* rows per 'frame' (one hop of audio)                                      */
     int32_t external;    /* -1: lives in the arena; >= 0: index into step()'s ext[] (rows = frames*rate, cursor 0) */
     int64_t arena_off;   /* float offset of this ring in the arena (batch * rows * channels floats)  */
+    int32_t extra_rows;  /* arena rings: rows beyond hist + max_frames * rate.  A ring with k * max_frames * rate extra rows still holds
+                            the history of the step k steps back when the steps since have all been taken: adk_program_rewind can then be
+                            applied k + 1 times in a row (the deferred guard of audiodec_amd/pipeline.py checks a step one to `depth` steps
+                            late and repeats what followed it); 0 for external rings                                             */
+    int32_t reserved_;   /* 0 */
 } adk_ring_desc;
 
 enum { ADK_OP_CONV = 0, ADK_OP_RING_WRITE = 1, ADK_OP_MEAN = 2,
@@ -259,10 +264,10 @@ typedef struct {
                                             ONE kernel (csrc/conv_rb16.hip: activations resident in LDS; an intermediate ring then receives
                                             only the rows later calls need as history).  0 / 1: no chain starts here */
     int32_t in_shadow, out_shadow;       /* 1 + id of the SHADOW ring of in_ring / out_ring, 0 = none (ADK_IMPL_SPLIT16* ops only).  A shadow
-                                            ring has the geometry of its ring (channels, hist, rate) and holds, per 4-channel group of a row
-                                            (16 bytes, where the ring holds 4 floats), [4 x f16 hi][4 x f16 lo] of act(x): the split-f16 operand
-                                            form the readers would otherwise recompute for every element they stage, once per tap and per
-                                            64-row tile of outputs.  out_shadow: this op writes it beside its output (stream-K kernel only:
+                                            ring has the geometry of its ring (channels, hist, rate, extra_rows; channels % 8 == 0) and holds, per
+                                            8-channel group of a row (32 bytes, where the ring holds 8 floats), [8 x f16 hi][8 x f16 lo] of act(x):
+                                            the split-f16 operand form the readers would otherwise recompute for every element they stage, once per
+                                            tap and per 64-row tile of outputs.  out_shadow: this op writes it beside its output (stream-K kernel only:
                                             give such an op impl = ADK_IMPL_SPLIT16_SK; every op that writes the ring must carry it);
                                             in_shadow: the stream-K kernel stages from it instead of converting (other kernels ignore it:
                                             the ring itself is always complete).  Results are bit-identical with and without. */
@@ -270,13 +275,18 @@ typedef struct {
     float shadow_slope;
 } adk_op_desc;
 
-/* rows of ring i = hist + max_frames * rate (arena rings). */
+/* rows of ring i = hist + max_frames * rate + extra_rows (arena rings). */
 int adk_program_create(const adk_op_desc* ops, int32_t n_ops, const adk_ring_desc* rings, int32_t n_rings,
                        int32_t batch, int32_t max_frames, const float* weights, int64_t weights_floats,
                        float* arena, int64_t arena_floats, adk_program** out);
 void adk_program_destroy(adk_program* p);
 /* one call = `frames` hops for every stream; ext[i] are the external buffers named by the descs */
 int adk_program_step(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream);
+/* The same with options.  ADK_STEP_REPLAY: the ADK_OP_RING_WRITE ops are skipped -- the caller's input rows of this step are still in
+ * their rings (a step that is being REPEATED after adk_program_rewind: the rows it wrote then are the rows it would write now), so the
+ * repeat does not depend on the caller having kept its input buffer unchanged; ext[] entries read only by those ops may be NULL. */
+enum { ADK_STEP_REPLAY = 1 };
+int adk_program_step_ex(adk_program* p, int32_t frames, void* const* ext, int32_t n_ext, void* stream, int32_t step_flags);
 /* reset_buffer(): zero all history (AudioDec.py:250-256, HiFiGAN.py:298-305) */
 int adk_program_reset(adk_program* p, void* stream);
 /* The launches of a program report device-side failures to a sticky word of the PROGRAM (same bits as adk_debug_flags, which
@@ -289,6 +299,16 @@ int adk_program_reset(adk_program* p, void* stream);
  * it exactly; audiodec_amd/stream_generator.py does that automatically for synchronous callers ("guard"). */
 int adk_program_flags(adk_program* p, void* stream, int32_t* out);
 int adk_program_rewind(adk_program* p, int32_t frames);
+/* The DEFERRED form of adk_program_flags, for callers that keep several steps in flight (audiodec_amd/pipeline.py).
+ * adk_program_flags_post enqueues, behind the launches of the step(s) just issued on `stream`, one 1-thread kernel that exchanges the
+ * program's word for 0 and stores the old value in a pinned host word of this post, followed by an event; nothing waits.  *ticket
+ * names the post (tickets count up from 0; the host words of the last ADK_POST_SLOTS posts are kept).
+ * adk_program_flags_poll(ticket, block): *done = 1 and *flags = that word once the event has completed (block != 0: wait for it),
+ * else *done = 0.  ADK_ERR_STATE for a ticket that was never issued or whose slot has been reused.  A word covers what the program's
+ * launches reported between the previous post (or adk_program_flags) and this one. */
+enum { ADK_POST_SLOTS = 32 };
+int adk_program_flags_post(adk_program* p, void* stream, int64_t* ticket);
+int adk_program_flags_poll(adk_program* p, int64_t ticket, int32_t block, int32_t* done, int32_t* flags);
 /* "Fresh" = no step since create / reset: the one state bit of a program besides its arena and cursors (the offline lowering's
  * ADK_OP_HIST_REPLICATE -- the replication pad of CausalConvTranspose1d.forward, layers/conv_layer.py:189-192 -- runs on a fresh
  * step only).  adk_program_rewind restores the value from before the rewound step; get / set carry it over to a program that

@@ -45,7 +45,7 @@ def test_abi_version_and_struct_sizes(lib):
     # layout the C side compiles to (x86-64): see include/audiodec_hip.h
     assert C.sizeof(native.RingView) == 24
     assert C.sizeof(native.ConvDesc) == 80
-    assert C.sizeof(native.RingDesc) == 24
+    assert C.sizeof(native.RingDesc) == 32 and native.RingDesc.extra_rows.offset == 24      # (ABI 13: extra_rows behind arena_off)
     assert C.sizeof(native.OpDesc) == 208 and native.OpDesc.chain.offset == 184 and native.OpDesc.fuse_next.offset == 180
     assert native.OpDesc.in_shadow.offset == 188 and native.OpDesc.shadow_slope.offset == 200
     # ... and what gcc makes of the header itself (the header is C: a maintainer's cgo / ctypes stub sees these numbers)
@@ -58,7 +58,7 @@ def test_abi_version_and_struct_sizes(lib):
                      'sizeof(adk_conv_desc), sizeof(adk_ring_desc), sizeof(adk_op_desc), offsetof(adk_op_desc, chain), ADK_ABI_VERSION);return 0;}\n')
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", os.path.join(td, "sz")], check=True)
         out = subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout.split()
-    assert [int(v) for v in out] == [24, 80, 24, 208, 184, native.ABI_VERSION]
+    assert [int(v) for v in out] == [24, 80, 32, 208, 184, native.ABI_VERSION]
 
 
 def test_argument_validation_without_device(lib):
@@ -71,6 +71,9 @@ def test_argument_validation_without_device(lib):
     rc = lib.adk_program_create(None, 0, None, 0, 1, 1, None, 0, None, 0, C.byref(h))
     assert rc == -1 and b"null" in lib.adk_last_error()
     assert lib.adk_program_step(None, 1, None, 0, None) == -1
+    assert lib.adk_program_step_ex(None, 1, None, 0, None, 1) == -1
+    t = C.c_int64(0)
+    assert lib.adk_program_flags_post(None, None, C.byref(t)) == -1 and lib.adk_program_flags_poll(None, 0, 0, None, None) == -1
     assert lib.adk_rvq_encode(None, None, None, None, None, 1, 8, 64, 1024, None) == -1
     d = native.ConvDesc()
     v = native.RingView()

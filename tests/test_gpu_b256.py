@@ -43,7 +43,7 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
     old = os.environ.get("ADK_VOCODER_STAGES")
     os.environ["ADK_VOCODER_STAGES"] = "2"                     # bench.py --stages 2 (its default)
     try:
-        ad = load_audiodec(ckpt_root, bench.MODEL, seed, B, 1, split16, guard=False)      # as bench.py: nothing synchronises between steps
+        ad = load_audiodec(ckpt_root, bench.MODEL, seed, B, 1, split16)      # as bench.py: AudioDec's default guard, deferred by the pipeline object
     finally:
         if old is None:
             del os.environ["ADK_VOCODER_STAGES"]
@@ -51,6 +51,7 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
             os.environ["ADK_VOCODER_STAGES"] = old
     assert ad.decoder.stages == 2
     pipe = bench.TxRxPipeline(ad, DEV)                         # streams / workgroup share exactly as bench.py sets them up
+    assert pipe.deferred and pipe.depth == 4                   # nothing synchronises between steps; every program step is checked one to four batches late
     assert ad.decoder.workgroups == 0 and ad.tx_encoder.workgroups == 0      # (library default since round 2: no cap)
     kern = _program_kernels(ad)
     names = {k for _, k, _, _ in kern}
@@ -84,6 +85,7 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
             zs.append(pipe.last_z); idxs.append(pipe.last_idx)
         pipe.exit()
         torch.cuda.synchronize()
+    assert pipe.log.verified == steps and pipe.log.repairs == 0
     z = torch.cat([t.cpu() for t in zs], -1).numpy()
     idx = torch.cat([t.cpu() for t in idxs], -1).numpy()
     y = torch.cat([t.cpu() for t in ys], -1).numpy()

@@ -50,7 +50,7 @@ def _pipeline_run(ckpt_root, xs, steps):
     old = os.environ.get("ADK_VOCODER_STAGES")
     os.environ["ADK_VOCODER_STAGES"] = "2"                      # bench.py's default lowering
     try:
-        ad = load_audiodec(ckpt_root, bench.MODEL, bench.SEED, B, 1, True, guard=False)
+        ad = load_audiodec(ckpt_root, bench.MODEL, bench.SEED, B, 1, True)         # the default guard, deferred by the pipeline: what bench.py times
     finally:
         if old is None:
             del os.environ["ADK_VOCODER_STAGES"]
@@ -59,7 +59,7 @@ def _pipeline_run(ckpt_root, xs, steps):
     names = _chain_kernels(ad)
     assert {"conv_rb16<32>", "conv_rb16<64>", "conv_rb16<128>", "conv_ou16<192>", "conv_sk16<64x64>"} <= names, names
     pipe = bench.TxRxPipeline(ad, DEV)
-    assert len(pipe._all()) == 3
+    assert len(pipe._all()) == 3 and pipe.deferred
     zs, idxs, ys = [], [], []
     with torch.no_grad():
         torch.cuda.synchronize()
@@ -70,6 +70,7 @@ def _pipeline_run(ckpt_root, xs, steps):
         pipe.exit()
         torch.cuda.synchronize()
     assert native.device_flags() == 0
+    assert pipe.log.verified == steps and pipe.log.repairs == 0
     return torch.cat(zs, -1), torch.cat(idxs, -1), torch.cat(ys, -1)
 
 
