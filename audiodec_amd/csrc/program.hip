@@ -138,7 +138,6 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
-        if (conv_gk16_preferred(a)) return "conv_gk16<128x128>";
         return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
     }
     const bool mf = impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (impl == ADK_IMPL_MFMA || impl == ADK_IMPL_MFMA_ROWS || a.groups * a.cout_g >= 32);
@@ -161,7 +160,6 @@ extern "C" int adk_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_blocks")) { g_chain_min_blocks = value < 0 ? 0 : value; return ADK_OK; }
-    if (!strcmp(name, "gk16")) { conv_gk16_mode(value); return ADK_OK; }
     {
         const int r = rvq_set_option(name, value);
         if (r == 0) return ADK_OK;

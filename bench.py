@@ -187,8 +187,6 @@ def _rocprof_name(dom):
         return ("conv_up16_kernel<",)
     if dom.startswith("conv_ou16<"):
         return ("conv_ou16_kernel<",)
-    if dom.startswith("conv_gk16<"):
-        return ("conv_gk16_kernel",)
     return None
 
 
@@ -212,6 +210,26 @@ def _digest_now():
     return g.kernel_source_digest()[:16]
 
 
+BENCH_CONFIG = None        # set by main(): what tools/profile_round.sh records as `# bench_config:` in the captures it writes
+
+
+def bench_config_string(streams, stages, fps, precision, guard, serial=False):
+    return f"streams={streams} stages={stages} frames_per_step={fps} precision={precision} guard={guard} rvq={os.environ.get('ADK_BENCH_RVQ', 'tx')}" + (" serial" if serial else "")
+
+
+def _capture_stale(meta):
+    """A committed capture is stale unless it was taken from THIS build of the kernels, THIS host-side lowering / schedule (schedule_digest)
+    and the bench configuration of this run (captures from before round 5 carry no schedule digest: stale by definition once it matters)."""
+    import __graft_entry__ as g
+    if meta.get("source_digest", "").split()[0:1] != [_digest_now()]:
+        return True
+    if meta.get("schedule_digest", "").split()[0:1] != [g.schedule_digest()[:16]]:
+        return True
+    cfg = meta.get("bench_config", "unknown")
+    want = (BENCH_CONFIG or "").replace(" serial", "")
+    return cfg.replace(" serial", "") != want
+
+
 def pmc_traffic(dom):
     """HBM-side bytes per launch of kernel `dom` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for 16 B/lane streaming reads, + WRITE_SIZE), launch-weighted mean over ALL its launches between the two
@@ -228,7 +246,7 @@ def pmc_traffic(dom):
             n = float(r["launches"])
             num += n * (float(r["FETCH_KB_x2_corrected"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
             den += n
-    stale = meta.get("source_digest", "").split()[0:1] != [_digest_now()]
+    stale = _capture_stale(meta)
     return (round(num / den) if den else None), stale
 
 
@@ -244,7 +262,7 @@ def rocprof_duration(dom, stats_file=None):
     for r in rows:
         if all(t in r["kernel"] for t in sub):
             num += float(r["total_us"]); den += float(r["launches"])
-    stale = meta.get("source_digest", "").split()[0:1] != [_digest_now()]
+    stale = _capture_stale(meta)
     return (round(num / den, 2) if den else None), stale
 
 
@@ -452,7 +470,7 @@ def convtr_standalone(dev, sd_dec, B, fps, split16, iters=300):
     return us, m.last_kernel
 
 
-def convtr_t5(root, dev, sd_dec, B, split16, fps=5):
+def convtr_t5(root, dev, sd_dec, B, split16, fps=5, check=True):
     """Secondary roofline of the north-star's named kernel at the reference streamer's DEFAULT chunk: demoStream.py:28 frame_size = 1500
     samples = 5 hops per call (T = 5), where one launch of upsamples.3 moves 5x the rows of the headline's single-frame step.  A second
     model (max_frames = 5) is profiled per op on one HIP stream; the fused conv_out + upsamples.3 launch takes at most 128 input steps per
@@ -463,7 +481,8 @@ def convtr_t5(root, dev, sd_dec, B, split16, fps=5):
     for i in range(4):
         step(ad5, xs5[i % 2])
     torch.cuda.synchronize()
-    rows5 = op_profile(ad5, xs5, B, 6, fps)
+    with unguarded(ad5):
+        rows5 = op_profile(ad5, xs5, B, 6, fps)
     launches, by, ev = kernel_table(rows5, B, fps)
     res = convtr_roofline(launches, None, ev, ev, B, fps) or {}
     for k in ("frac_pipelined", "frac_serial", "frac_events_pipelined", "avg_launch_us_pipelined", "avg_launch_us_serial", "avg_launch_us_events_pipelined",
@@ -491,6 +510,13 @@ def convtr_t5(root, dev, sd_dec, B, split16, fps=5):
     res["frames_per_step_per_stream"] = fps
     res["pipeline_frames_per_s"] = round(B * fps * n / e, 1)
     res["pipeline_ms_per_step"] = round(1e3 * e / n, 4)
+    if check:
+        # this configuration selects other kernels than the headline (conv_up16 instead of conv_ou16, longer time tiles in the chains): it is
+        # checked against the CPU oracle in its own right -- fresh model, same stream count, same schedule object, 2 steps of 5 frames
+        c = self_check(root, dev, B, fps, False, steps=2)
+        res["self_check"] = {k: c[k] for k in ("ok", "streams", "steps", "max_abs_dz", "max_abs_dy", "indices_equal", "frames_with_flipped_indices",
+                                               "unexplained_flips", "rvq_decisions", "min_reference_top2_margin", "oracle_cpu_s")}
+        res["self_check"]["frames_per_step_per_stream"] = fps
     res["what"] = (f"the same workload at {fps} frames per stream per call (demoStream.py:28: frame_size 1500 = 5 hops, the reference streamer's default "
                    "chunk); serial per-op HIP events + the kernel alone; NOT the headline configuration (1 frame per call)")
     return res
@@ -635,6 +661,47 @@ def self_check(root, dev, B, fps, serial, steps=2, model=None, decode=True):
                     "vs the CPU oracle (oracle/audiodec_oracle.py)"}
 
 
+def self_check_vocoder(root, dev, B, steps=2):
+    """Parity of BASELINE config 4 (the v1 vocoder alone, codes -> waveform): a fresh model decodes `steps` batches of seeded random codes;
+    lookup sum and waveform against the CPU oracle (lookup: bit-exact -- the same additions in the same order, layers/vq_module.py:159-161;
+    waveform <= 1e-4 max-abs)."""
+    from audiodec_amd import synth, configs
+    from oracle import audiodec_oracle as O
+    keep = os.environ.get("ADK_VOCODER_STAGES")
+    os.environ["ADK_VOCODER_STAGES"] = "1"
+    try:
+        ad = build_audiodec(root, dev, B, 1, model="vctk_v1")
+    finally:
+        if keep is None:
+            os.environ.pop("ADK_VOCODER_STAGES", None)
+        else:
+            os.environ["ADK_VOCODER_STAGES"] = keep
+    g = torch.Generator().manual_seed(SEED + 4)
+    idxs = [torch.randint(0, 1024, (8, B, 1), generator=g) + 1024 * torch.arange(8).view(8, 1, 1) for _ in range(steps)]
+    zqs, ys = [], []
+    for idx in idxs:
+        zq = ad.rx_encoder.lookup(idx.to(dev))
+        zqs.append(zq); ys.append(ad.decoder.decode(zq))
+    torch.cuda.synchronize()
+    _, enc_tag, _, dec_tag, _ = configs.alias("vctk_v1")
+    mt_d, _, pd = configs.experiment(dec_tag)
+    _, _, pe = configs.experiment(enc_tag)
+    t0 = time.perf_counter()
+    tx = O.AutoEncoderOracle(synth.synth_state_dict(enc_tag, SEED), pe, 1)
+    zq0 = tx.initial_encoder(8192)
+    dec = O.build_decoder_oracle(synth.synth_state_dict(dec_tag, SEED), mt_d, pd, 1)
+    dec.initial_decoder(zq0)
+    dec = _widen(dec, B)
+    dq = dy = 0.0
+    with torch.no_grad():
+        for j in range(steps):
+            ozq = tx.lookup(idxs[j])
+            dq = max(dq, float((zqs[j].cpu() - ozq).abs().max()))
+            dy = max(dy, float((ys[j].cpu() - dec.decode(ozq)).abs().max()))
+    return {"ok": dq == 0.0 and dy < 1e-4, "model": "vctk_v1", "path": "codes -> lookup -> decode", "streams": B, "steps": steps,
+            "max_abs_dzq": dq, "max_abs_dy": dy, "oracle_cpu_s": round(time.perf_counter() - t0, 1)}
+
+
 def extra_configs(root, dev, steps=100, warmup=10, check=True):
     """SURVEY.md 8(d) configs 1-4 on this GPU in the arithmetic of the run (the headline is config 5's per-GPU share).  Configs 2 and 3
     -- whose stream counts (32, 64) select other kernels than the headline's 256: few-streams time tiles, no chain launches -- are also
@@ -726,6 +793,8 @@ def extra_configs(root, dev, steps=100, warmup=10, check=True):
         t = timed(lambda: ad.decoder.decode(zq), steps, warmup)
         res["cfg4_v1_vocoder_B256"] = {"ms_per_step": round(1e3 * t, 4), "frames_per_s": round(256 / t, 1),
                                        "tflops": round(596.8e6 * 256 / t / 1e12, 2)}
+        if check:
+            res["cfg4_v1_vocoder_B256"]["self_check"] = self_check_vocoder(root, dev, 256)
         del ad
     finally:
         if old_st is None:
@@ -845,6 +914,8 @@ def main():
     NG = args.groups
     assert B % NG == 0
     FPS = args.frames_per_step
+    global BENCH_CONFIG
+    BENCH_CONFIG = bench_config_string(B, args.stages, args.frames_per_step, args.precision, args.guard, args.serial)
     guard_arg = {"default": None, "off": False}[args.guard]
     ads = [build_audiodec(tmp.name, dev, B // NG, FPS, guard=guard_arg) for _ in range(NG)]
     ad = ads[0]
@@ -997,7 +1068,7 @@ def main():
                 out["roofline_convtr"] = roof_ct
                 out["kernels"] = kernels
                 if rank == 0 and world == 1 and FPS == 1 and not args.no_t5:
-                    out["roofline_convtr_T5"] = convtr_t5(tmp.name, dev, sds[dec_tag], B, args.precision == "split16")
+                    out["roofline_convtr_T5"] = convtr_t5(tmp.name, dev, sds[dec_tag], B, args.precision == "split16", check=not args.no_self_check)
                 enc_ms = sum(r["ms"] for r in rows if r["prog"] == "encoder")
                 dec_ms = sum(r["ms"] for r in rows if r["prog"].startswith("decoder"))
                 out["latency_ms"]["encoder_kernels_at_batch"] = round(enc_ms, 4)
@@ -1139,6 +1210,8 @@ def main():
     assert flags.value == 0, f"device error flags {flags.value}: results invalid"
     if "self_check" in out:
         assert out["self_check"]["ok"], f"parity check of the timed configuration failed: {out['self_check']}"
+    if "self_check" in out.get("roofline_convtr_T5", {}):
+        assert out["roofline_convtr_T5"]["self_check"]["ok"], f"parity check of the 5-frames-per-call configuration failed: {out['roofline_convtr_T5']['self_check']}"
     for k_, v_ in out.get("extra_configs", {}).items():
         if isinstance(v_, dict) and "self_check" in v_:
             assert v_["self_check"]["ok"], f"parity check of {k_} failed: {v_['self_check']}"

@@ -78,11 +78,6 @@ int adk_set_conv_cfg(int32_t cfg);
  *                         default was 160 -- with the chain kernels of that time the per-op launches, which spread a stream's time tiles
  *                         over many CUs, were faster below it; now the chain is faster at every launch size: 1 stream 0.74 -> 0.71 ms per
  *                         frame, 48 streams 0.86 -> 0.77 ms, profiles/r4_few_streams.md)
- *   "gk16"                the DMA-fed 128 x 128-tile kernel for convs whose input ring has a shadow (csrc/conv_mfma.hip, conv_gk16):
-*                         0 never (default: the stream-K kernel takes them), 1 where it is preferred (the wide layers with enough
- *                         tiles x K chunks to fill the chip: faster alone on the chip, slower beside two other programs), 2 wherever it
- *                         is supported (tests).  Results of the two kernels agree to
- *                         f32 round-off (K is cut elsewhere), each is bit-reproducible.
  *   "rvq_rows"            rows per workgroup of the residual-VQ search when dim == 64, size == 1024 (csrc/rvq.hip, rvq_encode_v4): from
  *                         "rvq_v4_min" rows (default 192) on, 2 or 4 rows share a workgroup's code registers; 1 (default) = 2 up to 512
  *                         rows, 4 above; 0: the round-3 kernels at every row count.  Indices and zq are bit-identical either way.

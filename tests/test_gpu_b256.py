@@ -69,8 +69,8 @@ def test_benched_configuration_matches_oracle(gpu, ckpt_root, split16):
             assert by_name[head] == f"conv_rb16<{C_}>", (head, by_name[head])
         for tail in ("encoder.conv_blocks.0.res_units.0.conv2", "encoder.conv_blocks.2.res_units.2.conv2", "blocks.1.convs2.2", "blocks.3.convs1.1"):
             assert by_name[tail] == "(fused into the previous op)", (tail, by_name[tail])
-        # the wide grouped convs of stage 0 read shadow rings: DMA-fed 128 x 128 tiles (conv_gk16); encoder block 3 stays on the stream-K kernel
-        assert by_name["blocks.0.convs1.0"] in ("conv_gk16<128x128>", "conv_sk16<64x64>") and by_name["encoder.conv_blocks.3.res_units.0.conv1"] == "conv_sk16<64x64>"
+        # the wide grouped convs of stage 0 and encoder block 3 read shadow rings on the stream-K kernel
+        assert by_name["blocks.0.convs1.0"] == "conv_sk16<64x64>" and by_name["encoder.conv_blocks.3.res_units.0.conv1"] == "conv_sk16<64x64>"
         assert sum(1 for _, k, _, _ in kern if k != "(fused into the previous op)") <= 45 - 5 - 1  # launches per step incl. ring writes, RVQ, lookup
     else:
         assert {"conv_rl<32>", "conv_rl<64>", "conv_sk<64x64>"} <= names, names
@@ -459,7 +459,6 @@ def test_shadow_rings_are_bit_identical(gpu, ckpt_root, monkeypatch, model, B, m
     second encoding of the same rows): latent, indices and waveform are compared bit for bit."""
     from audiodec_amd import program, native
     seed = 1337
-    native.set_option("gk16", 0)                                # the stream-K kernel on both sides: same kernel, same K cuts -> same bits
     monkeypatch.setattr(program, "SHADOW_RINGS", True)
     ad1 = load_audiodec(ckpt_root, model, seed, B, max_frames, True)
     progs = [ad1.tx_encoder._encoder()] + (list(ad1.decoder._decoder_stages()) if hasattr(ad1.decoder, "_decoder_stages") else [ad1.decoder._decoder()])
@@ -470,10 +469,6 @@ def test_shadow_rings_are_bit_identical(gpu, ckpt_root, monkeypatch, model, B, m
         for i in range(pr.n_ops):
             if pr._ops[i].out_shadow:
                 assert pr.describe_op(i, 1).startswith("conv_sk16<"), (pr.op_names[i], pr.describe_op(i, 1))
-    native.set_option("gk16", 2)
-    n_gk = sum(1 for pr in progs for i in range(pr.n_ops) if pr._ops[i].kind == 0 and pr.describe_op(i, calls[0]).startswith("conv_gk16<"))
-    native.set_option("gk16", 0)
-    assert n_gk >= 5, n_gk                                      # (what the third run below puts on the DMA-fed kernel)
     monkeypatch.setattr(program, "SHADOW_RINGS", False)
     ad0 = load_audiodec(ckpt_root, model, seed, B, max_frames, True)
     progs0 = [ad0.tx_encoder._encoder()] + (list(ad0.decoder._decoder_stages()) if hasattr(ad0.decoder, "_decoder_stages") else [ad0.decoder._decoder()])
@@ -506,25 +501,4 @@ def test_shadow_rings_are_bit_identical(gpu, ckpt_root, monkeypatch, model, B, m
         assert torch.equal(z1, z0), f"call {k}: latent differs by {float((z1 - z0).abs().max()):.3e}"
         assert torch.equal(i1, i0), f"call {k}: indices differ"
         assert torch.equal(y1, y0), f"call {k}: waveform differs by {float((y1 - y0).abs().max()):.3e}"
-    assert native.device_flags() == 0
-    # ... and the DMA-fed 128 x 128 kernel (conv_gk16) on every op it supports, against the stream-K results: K is cut elsewhere, so
-    # equality is to f32 round-off -- 1e-5 on latent and waveform (the north-star's tolerance against the REFERENCE is 1e-4), and the
-    # indices may differ only where the latents do (a near-tie); run twice: bit-reproducible (the last arriver adds in part order)
-    try:
-        native.set_option("gk16", 2)
-        monkeypatch.setattr(program, "SHADOW_RINGS", True)
-        o2 = run(load_audiodec(ckpt_root, model, seed, B, max_frames, True))
-        o3 = run(load_audiodec(ckpt_root, model, seed, B, max_frames, True))
-    finally:
-        native.set_option("gk16", 0)
-    clean = torch.ones(B, dtype=torch.bool, device=DEV)        # streams whose codes have agreed so far (a flipped code decodes another signal from then on)
-    for k, ((z2, i2, y2), (z3, i3, y3), (z1, i1, y1)) in enumerate(zip(o2, o3, o1)):
-        assert torch.equal(z2, z3) and torch.equal(i2, i3) and torch.equal(y2, y3), f"call {k}: conv_gk16 is not reproducible"
-        assert float((z2 - z1).abs().max()) < 1e-5, f"call {k}: latent differs by {float((z2 - z1).abs().max()):.3e}"
-        if k == len(o2) - 1:
-            clean[:] = True                                     # (the last call follows a reset_buffer: every stream starts over)
-        same = (i2.reshape(i2.shape[0], B, -1) == i1.reshape(i1.shape[0], B, -1)).all(0).all(-1)      # per stream: all codes of this call agree
-        clean &= same
-        assert int(clean.sum()) >= B - max(1, B // 100), f"call {k}: {int((~clean).sum())} streams with other codes"
-        assert float((y2 - y1)[clean].abs().max()) < 1e-5, f"call {k}: waveform differs by {float((y2 - y1)[clean].abs().max()):.3e}"
     assert native.device_flags() == 0

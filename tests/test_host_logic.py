@@ -289,8 +289,10 @@ def test_pmc_summary_keeps_only_the_marked_region(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(tmp_path), str(out)], stdout=subprocess.DEVNULL)
     lines = out.read_text().splitlines()
     assert lines[0].startswith("# source_digest: ") and len(lines[0].split()[2]) == 16     # the build the capture belongs to (bench.py: traffic_stale)
-    assert lines[1].startswith("# region: launches between the two")
-    assert lines[3] == '"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,2,200,400,20'
+    # round 5: the host-side lowering / schedule and the bench configuration of the capture are recorded too (bench.py: _capture_stale)
+    assert lines[1].startswith("# schedule_digest: ") and len(lines[1].split()[2]) == 16 and lines[2].startswith("# bench_config: ")
+    assert lines[3].startswith("# region: launches between the two")
+    assert lines[5] == '"conv_sk_kernel<2, 2, 1, 2, true, 1>",122880,2,200,400,20'
     # tools/trace_summary.py: the same marker logic for a rocprofv3 --kernel-trace CSV (steady-state kernel durations)
     th = '"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X","Grid_Size_Y","Grid_Size_Z"\n'
     def trow(i, grid, name, t0, t1):

@@ -12,5 +12,4 @@ cp gpurun_out/${tag}_kernel_stats_steady.csv gpurun_out/${tag}_kernel_stats_seri
 bash tools/gpu_session.sh $tag bench
 ( timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_20_steps.json 2> gpurun_out/${tag}_bench_20_steps.err ); echo "bench20 rc=$?"
 python tools/rb16_trace.py 256 1 2>&1 | grep -v "^Load\|amdgpu.ids" > gpurun_out/${tag}_rb16_trace.log; echo "trace rc=$?"
-python tools/gk_trace.py 256 2>&1 | tail -9 > gpurun_out/${tag}_gk16_trace.log
 bash tools/gpu_session.sh $tag tests

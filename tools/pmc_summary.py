@@ -56,6 +56,9 @@ def main():
         rows.append((name, k[1], max(fa[1], wa[1]), round(fk), round(2 * fk), round(wk)))
     with open(out, "w") as fh:
         fh.write("# source_digest: %s   (sha256 of audiodec_amd/csrc/*.hip + headers at capture: bench.py marks roofline.traffic stale when the build differs)\n" % source_digest())
+        import __graft_entry__ as g_
+        fh.write("# schedule_digest: %s   (sha256 of the host sources that decide the launches of a step: pipeline.py, program.py, stream_generator.py, arch.py)\n" % g_.schedule_digest()[:16])
+        fh.write("# bench_config: %s\n" % os.environ.get("ADK_PROFILE_CONFIG", "unknown"))
         fh.write("# region: %s\n" % ("launches between the two bench.py --pmc-markers (the timed steps)" if MARKERS[0] == MARKERS[1] and MARKERS[1]
                                      else "ALL launches of the passes (markers not found in every pass)"))
         fh.write("kernel,grid_threads,launches,FETCH_SIZE_KB_avg,FETCH_KB_x2_corrected,WRITE_SIZE_KB_avg\n")

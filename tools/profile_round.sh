@@ -12,6 +12,8 @@ what=${2:-all}
 STEPS=40
 ARGS="--steps $STEPS --warmup 10 --pmc-markers --no-cpu-baseline --no-other-precision --no-op-profile --no-extra-configs --no-self-check --no-guarded --no-t5"
 mkdir -p $R/gpurun_out/$tag
+# what the summaries record as `# bench_config:` (bench.py: a capture of another configuration is stale); must match bench_config_string() of $ARGS
+export ADK_PROFILE_CONFIG="streams=256 stages=2 frames_per_step=1 precision=split16 guard=default rvq=${ADK_BENCH_RVQ:-tx}"
 if [ "$what" != "serial-only" ]; then
   timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/$tag/trace -o p --output-format csv -- python $R/bench.py $ARGS > $R/gpurun_out/${tag}_trace.log 2>&1
   echo "trace rc=$?"

@@ -49,6 +49,8 @@ def main():
     import __graft_entry__ as g
     with open(out, "w") as fh:
         fh.write("# source_digest: %s   (sha256 of audiodec_amd/csrc/*.hip + headers at capture)\n" % g.kernel_source_digest()[:16])
+        fh.write("# schedule_digest: %s   (sha256 of the host sources that decide the launches of a step: pipeline.py, program.py, stream_generator.py, arch.py)\n" % g.schedule_digest()[:16])
+        fh.write("# bench_config: %s\n" % os.environ.get("ADK_PROFILE_CONFIG", "unknown"))
         fh.write("# region: %s\n" % ("dispatches between the two bench.py --pmc-markers (the timed steps)" if marked else "ALL dispatches (markers not found)"))
         if t_first is not None:
             fh.write("# wall span of the region: %.1f us; summed kernel time %.1f us (kernels of three HIP streams overlap)\n" % ((t_last - t_first) / 1e3, total / 1e3))
