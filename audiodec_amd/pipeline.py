@@ -27,6 +27,7 @@ which is when a caller may let it leave the device.
 ``native.raise_on_device_flags``), as bench.py's `unguarded` leg does.
 """
 import collections
+import time
 import warnings
 
 import torch
@@ -140,6 +141,10 @@ class StreamingPipeline:
         self.deferred = self.guarded and room >= 1 and not offline
         self.depth = room if self.deferred else 0
         self.log = GuardLog(self.depth, self._poll, self._repair, self._drain) if self.deferred else None
+        # host-side accounting (seconds, since construction / reset_host_times()): t_issue = handing a batch's launches to the runtime,
+        # t_guard = reading / waiting for the posts of older batches at the entry of step() -- what a rank's Python costs per step
+        self.t_issue = self.t_guard = 0.0
+        self.n_steps = 0
 
     # ---- stream plumbing ----
     def _all(self):
@@ -165,11 +170,21 @@ class StreamingPipeline:
             self.log.collect(block=True)
 
     # ---- one batch ----
+    def reset_host_times(self):
+        self.t_issue = self.t_guard = 0.0
+        self.n_steps = 0
+
     def step(self, x):
         """x (B, C, frames*hop) on the device -> y (B, out, frames*hop); returns as soon as the work is enqueued."""
+        t0 = time.perf_counter()
+        self.n_steps += 1
         if self.log is None:
-            return self._issue(x, None)
+            y = self._issue(x, None)
+            self.t_issue += time.perf_counter() - t0
+            return y
         self.log.collect()
+        t1 = time.perf_counter()
+        self.t_guard += t1 - t0
         b = _Batch()
         self.tx._defer = self.dec._defer = b.steps
         try:
@@ -178,6 +193,7 @@ class StreamingPipeline:
             self.tx._defer = self.dec._defer = None
         b.x, b.y = x, y
         self.log.push(b)
+        self.t_issue += time.perf_counter() - t1
         return y
 
     def _issue(self, x, b):

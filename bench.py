@@ -33,6 +33,8 @@ PMC_TRAFFIC_FILE = "r4_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WR
 STEADY_STATS_FILE = "r4_kernel_stats_steady.csv"   # rocprofv3 --kernel-trace over the timed steps of the same schedule (tools/trace_summary.py)
 SERIAL_STATS_FILE = "r4_kernel_stats_serial.csv"   # ... of `bench.py --serial` (one HIP stream, nothing else on the chip)
 PMC_TRAFFIC_SCRIPT = "tools/profile_round.sh"
+# the same three captures of `bench.py --frames-per-step 5` (the reference streamer's default chunk): the secondary roofline of the named kernel
+T5_STEADY_STATS_FILE, T5_SERIAL_STATS_FILE, T5_PMC_TRAFFIC_FILE = "r5_kernel_stats_T5_steady.csv", "r5_kernel_stats_T5_serial.csv", "r5_pmc_traffic_T5.csv"
 
 def build_audiodec(root, device, streams, max_frames, model=None, guard=None):
     from audiodec_amd import synth
@@ -217,7 +219,7 @@ def bench_config_string(streams, stages, fps, precision, guard, serial=False):
     return f"streams={streams} stages={stages} frames_per_step={fps} precision={precision} guard={guard} rvq={os.environ.get('ADK_BENCH_RVQ', 'tx')}" + (" serial" if serial else "")
 
 
-def _capture_stale(meta):
+def _capture_stale(meta, config=None):
     """A committed capture is stale unless it was taken from THIS build of the kernels, THIS host-side lowering / schedule (schedule_digest)
     and the bench configuration of this run (captures from before round 5 carry no schedule digest: stale by definition once it matters)."""
     import __graft_entry__ as g
@@ -226,17 +228,17 @@ def _capture_stale(meta):
     if meta.get("schedule_digest", "").split()[0:1] != [g.schedule_digest()[:16]]:
         return True
     cfg = meta.get("bench_config", "unknown")
-    want = (BENCH_CONFIG or "").replace(" serial", "")
+    want = (config or BENCH_CONFIG or "").replace(" serial", "")
     return cfg.replace(" serial", "") != want
 
 
-def pmc_traffic(dom):
+def pmc_traffic(dom, traffic_file=None, config=None):
     """HBM-side bytes per launch of kernel `dom` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for 16 B/lane streaming reads, + WRITE_SIZE), launch-weighted mean over ALL its launches between the two
     --pmc-markers of those passes (= the timed steps of this same bench in the pipelined schedule; tools/pmc_summary.py).  PMC counters
     cannot be collected from inside this process.  Returns (bytes or None, stale): stale = the kernels were rebuilt from other
     sources since the capture (the file carries the source digest of its build)."""
-    rows, meta = _profile_csv(PMC_TRAFFIC_FILE)
+    rows, meta = _profile_csv(traffic_file or PMC_TRAFFIC_FILE)
     sub = _rocprof_name(dom)
     if rows is None or sub is None:
         return None, None
@@ -246,11 +248,11 @@ def pmc_traffic(dom):
             n = float(r["launches"])
             num += n * (float(r["FETCH_KB_x2_corrected"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
             den += n
-    stale = _capture_stale(meta)
+    stale = _capture_stale(meta, config)
     return (round(num / den) if den else None), stale
 
 
-def rocprof_duration(dom, stats_file=None):
+def rocprof_duration(dom, stats_file=None, config=None):
     """Average duration (us) of kernel `dom` over the timed steps of the bench, from a committed rocprofv3 kernel trace (profiles/
     STEADY_STATS_FILE: the pipelined schedule, SERIAL_STATS_FILE: `--serial`; the dispatch's own start/end, no launch gap, no event
     record), and whether that capture is stale."""
@@ -262,7 +264,7 @@ def rocprof_duration(dom, stats_file=None):
     for r in rows:
         if all(t in r["kernel"] for t in sub):
             num += float(r["total_us"]); den += float(r["launches"])
-    stale = _capture_stale(meta)
+    stale = _capture_stale(meta, config)
     return (round(num / den, 2) if den else None), stale
 
 
@@ -488,6 +490,22 @@ def convtr_t5(root, dev, sd_dec, B, split16, fps=5, check=True):
     for k in ("frac_pipelined", "frac_serial", "frac_events_pipelined", "avg_launch_us_pipelined", "avg_launch_us_serial", "avg_launch_us_events_pipelined",
               "rocprof_stale", "traffic"):
         res.pop(k, None)                   # (the committed traces / PMC passes are of the single-frame headline schedule)
+    # rocprofv3 evidence of THIS configuration: kernel traces (three-stream schedule and --serial) and PMC passes of
+    # `bench.py --frames-per-step 5 --pmc-markers` (tools/profile_round.sh, section T5), fresh when taken from this build / lowering
+    cfg5 = bench_config_string(B, os.environ.get("ADK_VOCODER_STAGES", "2"), fps, "split16" if split16 else "f32", "default")
+    kern5 = "conv_up16<64>"
+    bpl = res.get("bytes_per_launch")
+    rp_us, rp_stale = rocprof_duration(kern5, T5_STEADY_STATS_FILE, cfg5)
+    rs_us, rs_stale = rocprof_duration(kern5, T5_SERIAL_STATS_FILE, cfg5)
+    tr5, tr5_stale = pmc_traffic(kern5, T5_PMC_TRAFFIC_FILE, cfg5)
+    if bpl:
+        hb = lambda us_: round(bpl / (us_ * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us_ else None
+        res.update({"frac_pipelined": hb(rp_us), "frac_serial": hb(rs_us), "avg_launch_us_pipelined": rp_us, "avg_launch_us_serial": rs_us,
+                    "traffic": tr5, "traffic_stale": tr5_stale, "rocprof_stale": None if rp_stale is None and rs_stale is None else bool(rp_stale or rs_stale)})
+        if rp_us and rp_stale is False:
+            res.update({"frac": hb(rp_us), "achieved": round(bpl / (rp_us * 1e-6) / 1e9, 1), "avg_launch_us": rp_us, "frac_schedule": "pipelined",
+                        "frac_source": f"rocprofv3 kernel trace of the timed steps of bench.py --frames-per-step {fps}, three-stream schedule "
+                                       f"(profiles/{T5_STEADY_STATS_FILE}, same source / schedule digest as this build)"})
     us, kname = convtr_standalone(dev, sd_dec, B, fps, split16)
     b_alone = 4.0 * (64 * (100 * fps + 1) + 32 * 300 * fps) * B + 4.0 * 64 * 32 * 6
     res["transposed_conv_alone"] = {"kernel": kname, "avg_launch_us": round(us, 2), "bytes_per_launch": b_alone,
@@ -890,6 +908,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    # one rank per GPU, each on its own block of host cpus (ADK_BENCH_PIN=0: leave the affinity alone)
+    from audiodec_amd import shard as _shard
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pinned = _shard.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), local_world) if os.environ.get("ADK_BENCH_PIN", "1") != "0" else None
     coll_dev = dev if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
@@ -964,6 +986,8 @@ def main():
         sync_all()
         if args.pmc_markers:                       # outside the timed region: see tools/pmc_summary.py
             torch.arange(PMC_MARKER_N, device=dev); torch.cuda.synchronize()
+        if hasattr(pipe, "reset_host_times"):
+            pipe.reset_host_times()
         t0 = time.perf_counter()
         if pipe:
             pipe.enter()
@@ -978,6 +1002,10 @@ def main():
     elapsed_rank = elapsed
     elapsed = shard.max_over_ranks(elapsed, coll_dev)
     per_rank = shard.gather_floats(B * args.steps * FPS / elapsed_rank, coll_dev)      # every rank's own frames/s over ITS timed region
+    # what the Python of a rank costs per step: handing the launches of a batch to the runtime (issue) and reading the deferred checks of
+    # older batches (guard; includes waiting for the GPU when the host is `guard_depth` batches ahead) -- every rank's, gathered
+    host_issue = shard.gather_floats(1e3 * getattr(pipe, "t_issue", 0.0) / max(1, getattr(pipe, "n_steps", 1)), coll_dev) if hasattr(pipe, "t_issue") else None
+    host_guard = shard.gather_floats(1e3 * getattr(pipe, "t_guard", 0.0) / max(1, getattr(pipe, "n_steps", 1)), coll_dev) if hasattr(pipe, "t_issue") else None
     frames = world * B * args.steps * FPS
     ms_per_step = 1e3 * elapsed / args.steps
     out = {
@@ -1013,6 +1041,11 @@ def main():
                         if NG == 1 and getattr(pipe, "log", None) is not None else None),
         "frames_per_s_per_gpu": round(frames / elapsed / world, 1),
         "frames_per_s_of_each_rank": [round(v, 1) for v in per_rank],
+        "host_ms_per_step_of_each_rank": None if host_issue is None else {
+            "issue": [round(v, 4) for v in host_issue], "guard_polls_and_waits": [round(v, 4) for v in host_guard],
+            "cpus_of_rank_0": (f"{pinned[0]}-{pinned[-1]} ({len(pinned)} cpus, pinned)" if pinned else f"not pinned ({os.cpu_count()} host cpus)"),
+            "note": "issue = Python + runtime time to enqueue one batch (all programs, all HIP streams); must stay well below ms_per_step for the host not to be "
+                    "the bottleneck -- with N ranks on one host each rank is pinned to 1/N of the cpus (audiodec_amd/shard.py: pin_rank)"},
         "distributed": {"world_size": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
                         "ranks_per_gpu": 1, "steady_state_collectives": 0,
                         "note": "one process per GPU, streams [r*B, (r+1)*B) on rank r, full weight replica per rank; the collectives of a run are the "

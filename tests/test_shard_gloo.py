@@ -66,3 +66,14 @@ def test_stream_range_partitions_everything():
             for s in range(lo, hi):
                 assert shard.owner_of(s, n, w) == r
         assert seen == list(range(n))
+
+
+def test_rank_cpus_are_disjoint_equal_blocks():
+    """shard.rank_cpus: N ranks of one host get disjoint, equally sized, contiguous blocks of the cpus the launcher may use."""
+    cpus = list(range(3, 259))                                  # an affinity mask that does not start at 0
+    blocks = [shard.rank_cpus(r, 8, cpus) for r in range(8)]
+    assert all(len(b) == 32 for b in blocks) and blocks[0][0] == 3 and blocks[7][-1] == 258
+    assert sorted(c for b in blocks for c in b) == cpus
+    assert shard.rank_cpus(1, 3, list(range(10))) == [3, 4, 5]  # 10 // 3 = 3 each, one cpu left unused
+    assert shard.rank_cpus(0, 8, [0, 1]) == [0, 1]              # fewer cpus than ranks: no pinning
+    assert shard.pin_rank(0, 1) is None                         # a single rank is left alone
