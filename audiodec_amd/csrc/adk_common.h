@@ -88,7 +88,6 @@ int launch_conv_rl16_fused(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s
 bool conv_rb16_fusable(const ConvArgs* c, int n);
 int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s);   // ADK_ERR_STATE: not fusable for this call
 const char* conv_rb16_name(const ConvArgs* c, int n);
-int conv_rb16_set_option(const char* name, int value);   // 0 = set, 1 = not an option of the chain kernel
 // conv_out (1x1, 192 -> 64) + activation + the last up-sampler's transposed conv as one streaming launch (conv_ou16.hip)
 bool conv_ou16_fusable(const ConvArgs& a1, const ConvArgs& a2);
 int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s);     // ADK_ERR_STATE: not fusable for this call

@@ -41,12 +41,6 @@
 #ifndef ADK_RB16_PF128
 #define ADK_RB16_PF128 3           // (with the loads pinned: 2 / 3 / 4 / 5 / 6 -> 259.3 / 262.0 / 259.7 / 257.7 / ~250 k frames/s on one box; 6 was the unpinned choice)
 #endif
-#ifndef ADK_RB16_PF128B
-#define ADK_RB16_PF128B 4          // ... of the balanced 128-channel variant (one wave per SIMD, 9-12 MFMAs per step: 4 steps = 1150-1540 cycles ahead)
-#endif
-#ifndef ADK_RB16_EARLY128B
-#define ADK_RB16_EARLY128B false   // ... its residual (64 registers at four tiles) fetched behind the second conv's loop
-#endif
 #ifndef ADK_RB16_PIN_LOADS
 #define ADK_RB16_PIN_LOADS 1
 #endif
@@ -110,9 +104,7 @@ struct RbArgs {
     RbNode node[kRbMaxConvs + 1];        // node k = input of conv k, node k+1 = its output; node 2u = residual of conv 2u+1
     RbConv conv[kRbMaxConvs];
     int n_convs, batch, t, groups;
-    int spw;                             // streams per workgroup (the LDS layout is cut for this many)
-    int n_hi;                            // ragged split (128-channel chains of more (stream pair, group) items than CUs): the first n_hi workgroups
-                                         // of a group take spw streams, the others spw - 1; 0 = every workgroup takes spw
+    int spw;                             // streams per workgroup
     int hm;                              // history rows in front of a stream's new rows in LDS (max over convs)
     int rps;                             // LDS rows per stream = hm + t
     int n_tiles;                         // 32-column tiles of a full workgroup (ceil(spw * t / 32))
@@ -289,7 +281,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     constexpr bool BIAS_LDS = C < 128 && !(C == 64 && (SMAX == 2 || WR > 0));    // bias of every conv staged in LDS -- unless the LDS is needed to the last KB for a second / third workgroup per CU
     constexpr int RING_BYTES = WR * 4096;
     constexpr bool BIAS_LATE = WR > 0 && !BIAS_LDS;
-    constexpr bool HIST_LATE = (((WR > 0 || ADK_RB16_HIST_LATE > 1) && WPS == 3) || (C == 128 && (ADK_RB16_HIST_LATE128 || WPS == 1))) && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
+    constexpr bool HIST_LATE = (((WR > 0 || ADK_RB16_HIST_LATE > 1) && WPS == 3) || (C == 128 && ADK_RB16_HIST_LATE128)) && ADK_RB16_HIST_LATE;   // 168-register ring variants: the next conv's history rows are requested BEHIND the
                                                      // finish / ring-store pass instead of in front of it (16 registers less at the epilogue's peak)   // bias fetched BEHIND the MFMA loop (16 registers per lane would otherwise live through it)
     constexpr int NHP = (SMAX * kRbMaxHist * C8 + NT - 1) / NT;      // 8-channel history pieces per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char xs[];
@@ -301,9 +293,8 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     RB_STAMP(0);
 
     const int g = blockIdx.x % r.groups;
-    const int wg = blockIdx.x / r.groups;
-    const int b0 = (r.n_hi == 0 || wg < r.n_hi) ? wg * r.spw : r.n_hi * r.spw + (wg - r.n_hi) * (r.spw - 1);
-    const int scur = min((r.n_hi == 0 || wg < r.n_hi) ? r.spw : r.spw - 1, r.batch - b0);
+    const int b0 = (blockIdx.x / r.groups) * r.spw;
+    const int scur = min(r.spw, r.batch - b0);
     const int T = r.t;
     const int ncols = scur * T;
     float* bias_lds = reinterpret_cast<float*>(xs + (size_t)r.spw * r.rps * RS);      // [n_convs][C]
@@ -314,8 +305,7 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     // workgroup.  Everything below is straight-line for every wave: n-tiles the wave does not have and columns past the end are
     // computed on clamped addresses and masked where something is STORED (valid[]). ----
     const int mt = wave / WM, wi = wave - mt * WM;
-    const int n_tiles = r.n_hi ? (scur * T + 31) >> 5 : r.n_tiles;      // (ragged split: a workgroup with one stream less has fewer tiles to deal)
-    const int base = n_tiles / WM, rem = n_tiles - base * WM;
+    const int base = r.n_tiles / WM, rem = r.n_tiles - base * WM;
     const int pos = (wi + WM - (int)((blockIdx.x + blockIdx.x / 256u) % WM)) % WM;
     const int ntw = base + (pos < rem ? 1 : 0);
     const int first = pos * base + min(pos, rem);
@@ -668,14 +658,9 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     if (bad) atomicOr(r.err, 8);
 }
 
+struct RbPlan { int C, ta, tb, ntw, spw, n_tiles, hm, rps, wr; size_t lds; long long blocks; };
+
 int rb_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-
-struct RbPlan { int C, ta, tb, ntw, spw, n_hi, n_tiles, hm, rps, wr; size_t lds; long long blocks; };
-
-// adk_set_option("chain_balance", v) / ADK_RB16_BALANCE: 1 (default) = 128-channel chains with more workgroups than CUs at two streams per workgroup
-// are split into one workgroup per CU instead (3-4 streams each, see rb_plan); 0 = always two streams per workgroup (the round-3/4 split)
-static int g_rb_balance = -1;
-void rb_read_balance() { if (g_rb_balance < 0) g_rb_balance = rb_knob("ADK_RB16_BALANCE", 1) ? 1 : 0; }
 
 int rb_streams_per_wg(int C, int batch, int t) {
     static const int env128 = rb_knob("ADK_RB16_SPW", 0);        // tuning: streams per workgroup of the 128-channel chains
@@ -713,40 +698,18 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     const int T = a0.t_out;
     const int wm = 4 / (pl.C / 32);
     pl.spw = rb_streams_per_wg(pl.C, a0.batch, T);
-    pl.n_hi = 0;
+    pl.n_tiles = (pl.spw * T + 31) / 32;
+    pl.ntw = std::max(2, (pl.n_tiles + wm - 1) / wm);            // n-tiles per wave: 2, 3 or 4
+    if (pl.ntw > 4 || (pl.C == 128 && pl.ntw > 2)) return false;
     pl.hm = 0;
     for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
     if (pl.hm > kRbMaxHist) return false;
     pl.rps = pl.hm + T;
-    // Round 5, 128 channels: two streams per workgroup are 384 workgroups for the 256 x 3 (stream, group) items of a v1 vocoder's second stage --
-    // two per CU on half of the chip, one on the other half, and the launch lasts as long as the doubly loaded CUs (177 us for 139 us of mean
-    // work, profiles/r4_rb16_trace.log).  When there are more two-stream items than CUs the streams of a group are dealt to floor(256 / groups)
-    // workgroups instead -- ONE per CU, 3 or 4 streams each (the first batch % wgs workgroups take one more: they are dispatched first), up to
-    // four 32-column tiles per wave and the whole LDS of the CU (4 x 75 rows x 528 B).  A weight fragment then feeds 9-12 MFMAs instead of 6.
-    rb_read_balance();
-    if (pl.C == 128 && g_rb_balance && pl.spw == 2) {
-        const int wgs = 256 / std::max(1, a0.groups);
-        const long long two = (long long)((a0.batch + 1) / 2) * a0.groups;
-        if (two > 256 && wgs >= 1) {
-            const int lo = a0.batch / wgs, extra = a0.batch % wgs;          // lo or lo + 1 streams per workgroup
-            const int hi = lo + (extra ? 1 : 0);
-            const size_t lds_hi = (size_t)hi * pl.rps * (4 * 128 + 16) + kRbTouchSink;
-            if (lo >= 2 && (hi * T + 31) / 32 <= 4 && lds_hi <= 160 * 1024) { pl.spw = hi; pl.n_hi = extra; }
-        }
-    }
-    pl.n_tiles = (pl.spw * T + 31) / 32;
-    pl.ntw = std::max(2, (pl.n_tiles + wm - 1) / wm);            // n-tiles per wave: 2, 3 or 4
-    if (pl.ntw > 4 || (pl.C == 128 && pl.ntw > 2 && pl.spw <= 2)) return false;
     pl.wr = rb_ring_slots(pl.C, pl.ntw, pl.spw);
     const bool bias_lds = pl.C < 128 && !(pl.C == 64 && (pl.spw > 1 || pl.ntw > 2 || pl.wr > 0));        // (as BIAS_LDS of the instantiation rb_by_taps picks)
     pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0) + (size_t)pl.wr * 4096 + kRbTouchSink;
-    if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 4 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
+    if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 2 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
     pl.blocks = (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups;
-    if (pl.n_hi > 0 || (pl.C == 128 && pl.spw > 2)) {
-        // ragged: n_hi workgroups of spw streams, the rest spw - 1 (n_hi == 0 with spw > 2: batch divides evenly, all take spw)
-        const int wgs = pl.n_hi > 0 ? pl.n_hi + (a0.batch - pl.n_hi * pl.spw) / (pl.spw - 1) : a0.batch / pl.spw;
-        pl.blocks = (long long)wgs * a0.groups;
-    }
     return pl.blocks <= 0x7fffffffLL;
 }
 
@@ -842,7 +805,7 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
         cv.w_bytes = (unsigned)((unsigned long long)a.groups * (a.cout_g / 32) * cv.ksteps * 2048ull);
     }
     r.n_convs = n; r.batch = a0.batch; r.t = a0.t_out; r.groups = a0.groups;
-    r.spw = pl.spw; r.n_hi = pl.n_hi; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
+    r.spw = pl.spw; r.hm = pl.hm; r.rps = pl.rps; r.n_tiles = pl.n_tiles;
     r.slope = a0.slope; r.err = conv_err_word(a0);
     // L2 warm-up where a conv's weight block is a few loads per lane (32 / 64 channels) AND the launch is one workgroup per CU or
     // less (the encoder's chains: 256 workgroups, every round trip exposed -- encoder block 1 64 -> 68 us without it).  A touch is one
@@ -886,16 +849,7 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
         if (pl.ntw <= 3) return rb_by_taps<64, 3, 2, 2, 2, true, 0>(r, pl, act, s);
         return rb_by_taps<64, 4, 2, 2, 2, false, 0>(r, pl, act, s);
     }
-    // balanced split (round 5): one workgroup per CU, up to four tiles per wave, the residual early, registers to spare (512 per wave)
-    if (pl.spw > 2) return rb_by_taps<128, 4, 4, 1, ADK_RB16_PF128B, ADK_RB16_EARLY128B, 4>(r, pl, act, s);
     return rb_by_taps<128, 2, 2, 2, ADK_RB16_PF128, true, 4>(r, pl, act, s);
-}
-
-int conv_rb16_set_option(const char* name, int value) {
-    if (strcmp(name, "chain_balance")) return 1;
-    rb_read_balance();
-    g_rb_balance = value ? 1 : 0;
-    return 0;
 }
 
 const char* conv_rb16_name(const ConvArgs* c, int n) {

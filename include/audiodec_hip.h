@@ -78,9 +78,6 @@ int adk_set_conv_cfg(int32_t cfg);
  *                         default was 160 -- with the chain kernels of that time the per-op launches, which spread a stream's time tiles
  *                         over many CUs, were faster below it; now the chain is faster at every launch size: 1 stream 0.74 -> 0.71 ms per
  *                         frame, 48 streams 0.86 -> 0.77 ms, profiles/r4_few_streams.md)
- *   "chain_balance"       1 (default): a 128-channel residual chain with more two-stream workgroups than CUs (the second stage of a v1 vocoder from
- *                         171 streams on) runs as ONE workgroup per CU, 3-4 streams each (csrc/conv_rb16.hip: rb_plan); 0: always two streams per
- *                         workgroup.  Bit-identical either way (a column's sum does not depend on which tile it sits in).
  *   "rvq_rows"            rows per workgroup of the residual-VQ search when dim == 64, size == 1024 (csrc/rvq.hip, rvq_encode_v4): from
  *                         "rvq_v4_min" rows (default 192) on, 2 or 4 rows share a workgroup's code registers; 1 (default) = 2 up to 512
  *                         rows, 4 above; 0: the round-3 kernels at every row count.  Indices and zq are bit-identical either way.

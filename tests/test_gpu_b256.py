@@ -459,41 +459,6 @@ def test_survey_configs_2_and_3_match_oracle_at_their_stream_counts(gpu, ckpt_ro
     assert native.device_flags() == 0
 
 
-@pytest.mark.parametrize("B", [256, 171, 200])
-def test_balanced_128_channel_chain_is_bit_identical(gpu, ckpt_root, B):
-    """Round 5: a 128-channel residual chain with more two-stream workgroups than CUs (the second stage of the v1 vocoder from 171
-    streams on: HiFiGANResidualBlock.inference, residual_block.py:99-105, x 3 groups) is dealt to ONE workgroup per CU -- 3 or 4 streams
-    each, the first batch % workgroups of a group one more -- instead of two streams per workgroup (adk_set_option("chain_balance")).  A
-    column's sum does not depend on the tile it sits in: the vocoder's output must not move by a bit, over several steps (state rings:
-    the rows the chain leaves for later calls) and for stream counts that deal (4, 3, 3, ...), (3, 2, 2, ...) and (3, 3, 2, ...) streams."""
-    from audiodec_amd import native
-    old = os.environ.get("ADK_VOCODER_STAGES")
-    os.environ["ADK_VOCODER_STAGES"] = "1"
-    try:
-        ads = [load_audiodec(ckpt_root, "vctk_v1", 1337, B, 1, True, guard=False) for _ in range(2)]
-    finally:
-        if old is None:
-            del os.environ["ADK_VOCODER_STAGES"]
-        else:
-            os.environ["ADK_VOCODER_STAGES"] = old
-    pr = ads[0].decoder._decoder()
-    assert "conv_rb16<128>" in {pr.describe_op(i, 1) for i in range(pr.n_ops)}
-    g = torch.Generator().manual_seed(5)
-    outs = [[], []]
-    try:
-        with torch.no_grad():
-            for step in range(4):
-                idx = (torch.randint(0, 1024, (8, B, 1), generator=g) + 1024 * torch.arange(8).view(8, 1, 1)).to(DEV)
-                for k, ad in enumerate(ads):
-                    native.set_option("chain_balance", k)            # model 0: two streams per workgroup; model 1: balanced
-                    outs[k].append(ad.decoder.decode(ad.rx_encoder.lookup(idx)).clone())
-    finally:
-        native.set_option("chain_balance", 1)
-    for step, (a, b) in enumerate(zip(*outs)):
-        assert torch.equal(a, b), (step, float((a - b).abs().max()))
-    assert bool(torch.isfinite(outs[1][-1]).all()) and native.device_flags() == 0
-
-
 # ------------------------------------------------------------------------------------------------
 # shadow rings (adk_op_desc.in_shadow / out_shadow): the producer's epilogue stores the split-f16 operand form once, the
 # consumer stages it as it is -- the same values, so the outputs must not move by a bit

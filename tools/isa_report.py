@@ -16,8 +16,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 # WR > 0: the round-4 variants with the shared LDS weight ring
 IN_USE = {"Li32ELi2ELi11ELi11ELi3ELi1ELi2ELi2ELb0ELi0ELi0E": "vocoder stage 3 (32 ch, 3 tiles, register weight stream)",
           "Li64ELi2ELi11ELi11ELi2ELi1ELi3ELi1ELb1ELi0ELi3E": "vocoder stage 2 (64 ch, weight ring)",
-          "Li128ELi2ELi11ELi11ELi2ELi2ELi2ELi3ELb1ELi4ELi0E": "vocoder stage 1 (128 ch), two streams per workgroup (chain_balance = 0)",
-          "Li128ELi2ELi11ELi11ELi4ELi4ELi1ELi4ELb0ELi4ELi0E": "vocoder stage 1 (128 ch), balanced: one workgroup per CU, 3-4 streams (round 5)",
+          "Li128ELi2ELi11ELi11ELi2ELi2ELi2ELi3ELb1ELi4ELi0E": "vocoder stage 1 (128 ch)",
           "Li32ELi1ELi7ELi1ELi3ELi1ELi2ELi2ELb1ELi0ELi0E": "encoder block 0 (32 ch, 3 tiles)",
           "Li64ELi1ELi7ELi1ELi2ELi1ELi3ELi1ELb1ELi0ELi3E": "encoder block 1 (64 ch, weight ring)",
           "Li128ELi1ELi7ELi1ELi2ELi2ELi2ELi3ELb1ELi4ELi0E": "encoder block 2 (128 ch)",

@@ -49,7 +49,10 @@ def main():
     flags = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     lib_path = os.path.join(ROOT, "tools", "dbg", f"rb{flags}", "libaudiodec_hip.so")
-    os.environ["ADK_LIB_PATH"] = lib_path if os.path.exists(lib_path) else build_debug(flags)
+    if "ADK_TRACE_LIB" in os.environ:               # any other debug build (tools/alt_build.sh <name> conv_rb16 -DADK_RB16_DBG=1 ...)
+        os.environ["ADK_LIB_PATH"] = os.environ["ADK_TRACE_LIB"]
+    else:
+        os.environ["ADK_LIB_PATH"] = lib_path if os.path.exists(lib_path) else build_debug(flags)
     os.environ["ADK_SPLIT16"] = "1"
     os.environ.setdefault("ADK_VOCODER_STAGES", "1")
     import numpy as np
