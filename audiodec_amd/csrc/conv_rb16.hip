@@ -662,7 +662,7 @@ struct RbPlan { int C, ta, tb, ntw, spw, n_tiles, hm, rps, wr; size_t lds; long 
 
 int rb_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-int rb_streams_per_wg(int C, int batch, int t) {
+int rb_streams_per_wg(int C, int batch, int t, int groups) {
     static const int env128 = rb_knob("ADK_RB16_SPW", 0);        // tuning: streams per workgroup of the 128-channel chains
     static const int env64 = rb_knob("ADK_RB16_SPW64", 0);       // ... of the 64-channel chains
     int s = (C == 128) ? 2 : 1;
@@ -671,6 +671,12 @@ int rb_streams_per_wg(int C, int batch, int t) {
     const int wm = 4 / (C / 32);                                  // waves per m-tile, up to 4 n-tiles each
     const int max_ntw = C == 128 ? 2 : 4;                         // n-tiles per wave the instantiations go up to
     while (s > 1 && (s > batch || (s * t + 31) / 32 > max_ntw * wm)) --s;
+    // Round 5, few streams: a 128-channel launch of at most 128 (stream, group) items leaves half of the chip idle either way, and a workgroup's
+    // time is its MFMA loops over TWO 32-column tiles -- of which one stream of a 25-step frame fills 25 columns.  One stream per workgroup and ONE
+    // tile per wave (NTW = 1) halve the loops (single stream: 9.6 -> ~5 us per conv of the vocoder's second stage, profiles/r5_rb16_trace_single_stream.log)
+    // at twice the workgroups.  Larger launches keep two streams per workgroup: there the chip is full and a weight fragment should feed two tiles.
+    static const int few = rb_knob("ADK_RB16_FEW128", 128);
+    if (C == 128 && s == 2 && env128 <= 0 && (long long)batch * groups <= few && t <= 32) s = 1;
     return s;
 }
 
@@ -697,9 +703,9 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     pl.C = a0.cin_g; pl.ta = a0.taps; pl.tb = c[1].taps;
     const int T = a0.t_out;
     const int wm = 4 / (pl.C / 32);
-    pl.spw = rb_streams_per_wg(pl.C, a0.batch, T);
+    pl.spw = rb_streams_per_wg(pl.C, a0.batch, T, a0.groups);
     pl.n_tiles = (pl.spw * T + 31) / 32;
-    pl.ntw = std::max(2, (pl.n_tiles + wm - 1) / wm);            // n-tiles per wave: 2, 3 or 4
+    pl.ntw = std::max(pl.C == 128 ? 1 : 2, (pl.n_tiles + wm - 1) / wm);            // n-tiles per wave: 2, 3 or 4 (128 channels: 1 or 2)
     if (pl.ntw > 4 || (pl.C == 128 && pl.ntw > 2)) return false;
     pl.hm = 0;
     for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
@@ -849,6 +855,9 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
         if (pl.ntw <= 3) return rb_by_taps<64, 3, 2, 2, 2, true, 0>(r, pl, act, s);
         return rb_by_taps<64, 4, 2, 2, 2, false, 0>(r, pl, act, s);
     }
+    // few streams: one stream, one tile per wave.  (Deeper weight prefetch for these one-workgroup-per-CU launches -- 8 steps at 128 channels, 4 at 32, five
+    // ring slots at 64 -- measured 1-2 % SLOWER at 1 / 8 / 32 / 64 streams, round 5: the stream of one workgroup per CU is not bound by its round trips.)
+    if (pl.ntw == 1) return rb_by_taps<128, 1, 1, 2, ADK_RB16_PF128, true, 4>(r, pl, act, s);
     return rb_by_taps<128, 2, 2, 2, ADK_RB16_PF128, true, 4>(r, pl, act, s);
 }
 
