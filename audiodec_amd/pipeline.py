@@ -124,6 +124,11 @@ class StreamingPipeline:
         self.ad = ad
         self.tx, self.rx, self.dec = ad.tx_encoder, ad.rx_encoder, ad.decoder
         self.dev = torch.device(device) if device is not None else self.tx._dev()
+        for g_ in (self.tx, self.rx, self.dec):
+            d_ = getattr(g_, "_device", None)
+            if d_ is not None and torch.device(d_) != torch.device(self.tx._dev()):
+                # (the reference's --tx_cuda / --rx_cuda split runs the two halves on two GPUs: that is two pipelines joined by the wire, not this object)
+                raise native.NativeError("StreamingPipeline: transmitter and receiver must live on one HIP device")
         self.n_dec = getattr(self.dec, "stages", 1)
         pr = list(priorities) + [0, 0, 0, 0]
         pool = _pool_streams(self.dev, 1 + max(self.n_dec, 1), pr)
@@ -165,9 +170,19 @@ class StreamingPipeline:
         self.settle()
 
     def settle(self):
-        """Wait until every batch handed out so far is verified; results are final afterwards."""
+        """Wait until every batch handed out so far is verified; results are final afterwards.  Call it (or exit()) before anything that
+        changes the generators' state behind the pipeline's back -- reset_buffer(), reset_stream(), set_*() -- a repair of a batch that is
+        still unverified would rewind across it."""
         if self.log is not None:
             self.log.collect(block=True)
+
+    def __enter__(self):
+        self.enter()
+        return self
+
+    def __exit__(self, *exc):
+        self.exit()
+        return False
 
     # ---- one batch ----
     def reset_host_times(self):
