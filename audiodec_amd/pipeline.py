@@ -49,11 +49,12 @@ def _pool_streams(dev, n, priorities):
 
 class _Batch:
     """One step() in flight: the tensors handed out and the program steps taken for it."""
-    __slots__ = ("x", "z", "idx", "y", "steps")
+    __slots__ = ("x", "z", "idx", "y", "steps", "units")
 
-    def __init__(self):
+    def __init__(self, units=1):
         self.x = self.z = self.idx = self.y = None
         self.steps = []          # (program, frames, ticket), in issue order
+        self.units = units       # frames per stream of this batch: what a rewind of it takes out of the rings' extra rows
 
 
 class GuardLog:
@@ -63,9 +64,12 @@ class GuardLog:
     batches from the first bad one on (oldest first) and must leave them correct.  `culprit` = the first program, in issue order,
     that reported in the first bad batch: programs behind it (and the same programs in later batches) may only have seen its garbage."""
 
-    def __init__(self, depth, poll, repair, drain):
+    def __init__(self, depth, poll, repair, drain, budget=None):
+        """depth: most batches unverified at a time; budget: most UNITS (frames per stream, summed over the unverified batches) -- what the
+        rings can be rewound by; None = no limit besides depth."""
         assert depth >= 1
         self.depth, self._poll, self._repair, self._drain = int(depth), poll, repair, drain
+        self.budget = budget
         self.pending = collections.deque()
         self.verified = 0            # batches found clean (or repaired) so far
         self.repairs = 0
@@ -74,10 +78,14 @@ class GuardLog:
     def push(self, batch):
         self.pending.append(batch)
 
-    def collect(self, block=False):
-        """Retire the batches whose posts have completed; block=True (or a full log) waits for the oldest first."""
+    def units_pending(self):
+        return sum(b.units for b in self.pending)
+
+    def collect(self, block=False, incoming=0):
+        """Retire the batches whose posts have completed; block=True -- or a log that is full, or that could not be rewound any more with the
+        `incoming` units of the batch about to be issued on top -- waits for the oldest first."""
         while self.pending:
-            must = block or len(self.pending) >= self.depth
+            must = block or len(self.pending) >= self.depth or (self.budget is not None and self.units_pending() + incoming > self.budget)
             b = self.pending[0]
             flags, ready = 0, True
             for prog, _frames, ticket in b.steps:
@@ -145,7 +153,9 @@ class StreamingPipeline:
         offline = any(getattr(g, "offline", False) for g in gens)
         self.deferred = self.guarded and room >= 1 and not offline
         self.depth = room if self.deferred else 0
-        self.log = GuardLog(self.depth, self._poll, self._repair, self._drain) if self.deferred else None
+        # what the rings can be rewound by, in frames per stream: (rewind_depth + 1) x max_frames (rows = hist + that many frames)
+        self.budget = min([(getattr(g, "rewind_depth", 0) + 1) * getattr(g, "max_frames", 1) for g in gens]) if self.deferred else 0
+        self.log = GuardLog(self.depth, self._poll, self._repair, self._drain, self.budget) if self.deferred else None
         # host-side accounting (seconds, since construction / reset_host_times()): t_issue = handing a batch's launches to the runtime,
         # t_guard = reading / waiting for the posts of older batches at the entry of step() -- what a rank's Python costs per step
         self.t_issue = self.t_guard = 0.0
@@ -197,10 +207,17 @@ class StreamingPipeline:
             y = self._issue(x, None)
             self.t_issue += time.perf_counter() - t0
             return y
-        self.log.collect()
+        frames = -(-int(x.shape[-1]) // self.tx.hop)
+        if frames > self.budget:
+            # a batch longer than the rings can be rewound by (a whole utterance in one call): checked synchronously, step by step
+            self.log.collect(block=True)
+            y = self._issue(x, None)
+            self.t_issue += time.perf_counter() - t0
+            return y
+        self.log.collect(incoming=frames)
         t1 = time.perf_counter()
         self.t_guard += t1 - t0
-        b = _Batch()
+        b = _Batch(frames)
         self.tx._defer = self.dec._defer = b.steps
         try:
             y = self._issue(x, b)

@@ -23,10 +23,10 @@ pytestmark = pytest.mark.gpu
 HOP = 300
 
 
-def _run(ad, pipe, B, steps, seed, bad_x, bad_q, magic):
+def _run(ad, pipe, B, steps, seed, bad_x, bad_q, magic, frames=1):
     """bad_x = (batch, stream, factor); bad_q = (stream, factor): the zq of `stream` is scaled wherever its first emitted index
     equals `magic` -- a pure function of the codes, applied on the device without synchronising, so the repeat of a batch sees it too."""
-    audio = [np.stack([synth.synth_audio(seed + j, s, HOP) for s in range(B)]) for j in range(steps)]
+    audio = [np.stack([synth.synth_audio(seed + j, s, frames * HOP) for s in range(B)]) for j in range(steps)]
     if bad_x is not None:
         audio[bad_x[0]][bad_x[1]] *= bad_x[2]
     xs = [torch.from_numpy(a)[:, None, :].to(DEV) for a in audio]
@@ -61,13 +61,16 @@ def _run(ad, pipe, B, steps, seed, bad_x, bad_q, magic):
     return xs, [t.cpu() for t in zs], [t.cpu() for t in idxs], [t.cpu() for t in ys], warned
 
 
-@pytest.mark.parametrize("model,B,stages", [("vctk_v1", 256, "2"), ("vctk_sym", 8, "1")])
-def test_deferred_guard_repairs_overflows_in_the_pipelined_schedule(gpu, ckpt_root, model, B, stages):
+@pytest.mark.parametrize("model,B,stages,frames,max_frames", [("vctk_v1", 256, "2", 1, 1), ("vctk_sym", 8, "1", 1, 1), ("vctk_sym", 5, "1", 3, 2)],
+                         ids=["vctk_v1-256-2", "vctk_sym-8-1", "vctk_sym-5-three_frames_in_chunks_of_two"])
+def test_deferred_guard_repairs_overflows_in_the_pipelined_schedule(gpu, ckpt_root, model, B, stages, frames, max_frames):
+    """(third case: three frames per batch through programs that take two per step -- every batch is two program steps per program, of
+    2 and 1 frames, each with its own post; a repair rewinds them one by one)"""
     steps, seed = 9, 4242
     old = os.environ.get("ADK_VOCODER_STAGES")
     os.environ["ADK_VOCODER_STAGES"] = stages
     try:
-        ad = load_audiodec(ckpt_root, model, seed, B, 1, True)               # guard=None: the default, on
+        ad = load_audiodec(ckpt_root, model, seed, B, max_frames, True)      # guard=None: the default, on
     finally:
         if old is None:
             del os.environ["ADK_VOCODER_STAGES"]
@@ -82,7 +85,7 @@ def test_deferred_guard_repairs_overflows_in_the_pipelined_schedule(gpu, ckpt_ro
     # the oracle first: it says which code marks the batch whose zq is scaled
     tx, rx, dec = build_oracle_shared_warmup(model, B, seed)
     bad_x, q_stream, q_batch = (2, 1, 1e6), 2, 5
-    audio = [np.stack([synth.synth_audio(seed + j, s, HOP) for s in range(B)]) for j in range(steps)]
+    audio = [np.stack([synth.synth_audio(seed + j, s, frames * HOP) for s in range(B)]) for j in range(steps)]
     audio[bad_x[0]][bad_x[1]] *= bad_x[2]
     oz, oi, oy = [], [], []
     with torch.no_grad():
@@ -101,7 +104,7 @@ def test_deferred_guard_repairs_overflows_in_the_pipelined_schedule(gpu, ckpt_ro
     hits = [j for j in range(steps) if int(oi[j].reshape(oi[j].shape[0], B, -1)[0, q_stream, 0]) == magic]
     q_first = hits[0]                                          # (the marked code may occur in an earlier batch too: the rule is a function of the codes)
 
-    xs, zs, idxs, ys, warned = _run(ad, pipe, B, steps, seed, bad_x, (q_stream, 1e5), magic)
+    xs, zs, idxs, ys, warned = _run(ad, pipe, B, steps, seed, bad_x, (q_stream, 1e5), magic, frames)
     # the encoder overflowed in batch 2, the vocoder in batch q_first: one or two repairs (two overflows inside one window of unverified
     # batches are one repair), each announced at a LATER step or at exit() -- never in the step that issued the bad batch
     assert 1 <= pipe.log.repairs <= 2 and sum(warned) >= pipe.log.repairs, (pipe.log.repairs, warned)

@@ -107,6 +107,27 @@ def test_flags_of_later_batches_and_other_programs_reach_the_same_repair():
     assert repaired == [([2, 3], {"enc": 8, "dec": 10}, "enc")] and log.verified == 4 and log.repairs == 1
 
 
+def test_the_log_never_holds_more_units_than_the_rings_can_be_rewound_by():
+    """A batch of several frames takes several frames of the rings' extra rows: the log waits for old batches when the incoming one would
+    exceed the budget, whatever the batch count."""
+    enc = FakeProgram("enc")
+    repaired, drained = [], []
+
+    def poll(prog, ticket, block):
+        return prog.poll(ticket, block)
+    log = GuardLog(4, poll, lambda *a: repaired.append(a), lambda: drained.append(1), budget=10)
+    for n in range(6):
+        log.collect(incoming=3)
+        b = _Batch(3)
+        b.x = n
+        b.steps.append((enc, 2, enc.post())); b.steps.append((enc, 1, enc.post()))      # three frames as two program steps
+        log.push(b)
+        assert log.units_pending() <= 10 and len(log.pending) <= 3                        # 3 batches = 9 frames; a fourth would be 12
+    assert log.waits > 0 and not repaired
+    log.collect(block=True)
+    assert log.verified == 6
+
+
 def test_pipeline_is_only_deferred_when_the_rings_can_be_rewound():
     """Host-side contract of StreamingPipeline.__init__ (no device needed for the decision itself)."""
     import inspect
