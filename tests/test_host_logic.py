@@ -388,3 +388,16 @@ def test_shadow_ring_assignment_is_shape_only_and_consistent():
     bo = program.build_hifigan(synth.synth_state_dict(dec_tag, 1), pd, True, True)
     bo.assign_shadows()
     assert not bo.shadow_of and not any(op.in_shadow or op.out_shadow for op in bo.ops)
+
+
+def test_graph_ring_sizing_accounts_for_the_rewindable_rows():
+    """program.graph_ring_hist: with HIP-graph replay the ring length -- history + one step + the rewind_depth extra steps of the deferred guard
+    (adk_ring_desc.extra_rows) -- must be a small multiple of the per-step advance, and the history must not shrink below what the layers need."""
+    from audiodec_amd.program import graph_ring_hist, _NICE_PERIODS
+    for hist, rate, mf in ((54, 300, 1), (5, 100, 1), (50, 5, 2), (0, 1, 1), (2, 1, 16), (10, 25, 1)):
+        for depth in (0, 1, 4):
+            h = graph_ring_hist(hist, rate, mf, depth)
+            adv = mf * rate
+            rows = h + adv + depth * adv
+            assert h >= hist and rows % adv == 0 and rows // adv in _NICE_PERIODS, (hist, rate, mf, depth, h)
+            assert rows // adv <= max(q for q in _NICE_PERIODS if q >= -(-(hist + adv) // adv) + depth), (hist, rate, mf, depth)
