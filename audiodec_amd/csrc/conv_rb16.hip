@@ -688,9 +688,12 @@ int rb_streams_per_wg(int C, int batch, int t, int groups) {
 // Off for the three-tile 32-channel variant (two workgroups per CU, no spills to begin with): there the per-group barrier costs more
 // than the weight stream did (vocoder stage 3 139 -> 148 us) -- ADK_RB16_RING=2 switches it on for A/B, =0 switches all rings off.
 // 128 channels: every wave has an m-tile of its own, nothing to share.
-int rb_ring_slots(int C, int ntw, int spw) {
+// Round 5: not for launches of <= 128 workgroups (few streams: at most one workgroup on half of the CUs) -- the ring's hand-over per group (a counted
+// wait + a barrier every one or two 16-k steps) costs a lone workgroup more than the second weight stream did: 1 / 32 streams 0.715 / 0.761 ms per
+// step with the ring, 0.707 / 0.752 without (tools/r5_s12.sh).
+int rb_ring_slots(int C, int ntw, int spw, long long blocks) {
     static const int on = rb_knob("ADK_RB16_RING", 1);
-    if (!on) return 0;
+    if (!on || (blocks <= 128 && on < 3)) return 0;
     if (C == 32 && ntw == 2) return 3;
     if (C == 32 && ntw == 3 && on >= 2) return ADK_RB16_RING_SLOTS32;
     if (C == 64 && ntw == 2 && spw == 1) return 3;        // three 4 KiB slots is what three workgroups per CU leave room for
@@ -711,7 +714,7 @@ bool rb_plan(const ConvArgs* c, int n, RbPlan& pl) {
     for (int k = 0; k < n; ++k) pl.hm = std::max(pl.hm, (c[k].taps - 1) * c[k].dilation);
     if (pl.hm > kRbMaxHist) return false;
     pl.rps = pl.hm + T;
-    pl.wr = rb_ring_slots(pl.C, pl.ntw, pl.spw);
+    pl.wr = rb_ring_slots(pl.C, pl.ntw, pl.spw, (long long)((a0.batch + pl.spw - 1) / pl.spw) * a0.groups);
     const bool bias_lds = pl.C < 128 && !(pl.C == 64 && (pl.spw > 1 || pl.ntw > 2 || pl.wr > 0));        // (as BIAS_LDS of the instantiation rb_by_taps picks)
     pl.lds = (size_t)pl.spw * pl.rps * (4 * pl.C + 16) + (bias_lds ? (size_t)n * pl.C * 4 : 0) + (size_t)pl.wr * 4096 + kRbTouchSink;
     if (pl.lds > 160 * 1024 || pl.spw > (pl.C == 128 ? 2 : (pl.C == 64 ? 2 : 1))) return false;      // (SMAX of the instantiations)
@@ -822,7 +825,9 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     // profiles/r3_rb16_timeline.md) -- their waves walk the weights in lockstep instead (LS).
     // ADK_RB16_WARM: 0 never, 1 always, 2 = the round-3 rule (32 / 64 channels, any launch size).
     static const int warm_env = rb_knob("ADK_RB16_WARM", -1);
-    r.warm = warm_env == 2 ? (pl.C <= 64) : (warm_env >= 0 ? warm_env : (pl.C <= 64 && pl.blocks <= 384));
+    // Round 5: not for launches of <= 128 workgroups either (few streams) -- there the touches cost more than they save: 1 / 8 / 32 streams
+    // 0.719 / 0.750 / 0.772 ms per step with them, 0.713 / 0.746 / 0.761 without (tools/r5_s11.sh); with them on the 128-channel chains too: 0.760 / 0.824 / 0.818.
+    r.warm = warm_env == 2 ? (pl.C <= 64) : (warm_env >= 0 ? warm_env : (pl.C <= 64 && pl.blocks <= 384 && pl.blocks > 128));
 #if ADK_RB16_DBG & 1
     r.dbg_slot = g_rb_launch++;
 #endif
