@@ -110,6 +110,9 @@ struct RbArgs {
     int n_tiles;                         // 32-column tiles of a full workgroup (ceil(spw * t / 32))
     float slope; int* err;
     int warm;                            // touch the next conv's weights / the history rows ahead of use (launches of one workgroup per CU)
+    int n_main;                          // workgroups that compute: blocks [0, n_main)
+    int helpers;                         // > 0: blocks [8 * ceil(n_main / 8), ... + 8 * helpers) only warm the L2s (few streams; see the kernel head)
+    int helper_convs;                    // ... with the weights of convs [0, helper_convs)
     int dbg_slot;
 };
 
@@ -290,6 +293,39 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const unsigned lane16 = (unsigned)lane * 16u;
+    // ---- L2 warm-up by HELPER workgroups (round 5, launches of a few workgroups).  A chain of few streams is one workgroup per (stream, group) that
+    // pulls its convs' weights through ONE CU -- and between two steps they have left the L2s (a frame touches 93 MB of weights), so they come
+    // from the Infinity Cache at what one CU's request path gets out of it: 720 KB per conv of the vocoder's second stage in 9.6 us = 75 GB/s
+    // (profiles/r5_rb16_trace_single_stream.log), half of what the same path delivers from the L2.  The rest of the chip idles meanwhile.  So the launch
+    // carries `helpers` extra workgroups per XCD that do nothing but TOUCH -- one dword per 128-byte line, into a sink nobody reads -- the weights
+    // the computing workgroups of THEIR XCD will stream, conv after conv, and exit: the lines are then in that XCD's L2.  Which XCD a block runs
+    // on is an observation, not a contract (block b -> XCD b % 8, MI355X_MICROARCH.md): a wrong guess costs the speed-up, nothing else -- nothing
+    // that is computed depends on a helper. ----
+    if ((int)blockIdx.x >= r.n_main) {
+        const int pad = (r.n_main + 7) & ~7;
+        if (r.helpers <= 0 || (int)blockIdx.x < pad) return;
+        const int h = (int)blockIdx.x - pad, xcd = h & 7, sub = h >> 3;
+        typedef unsigned char __attribute__((address_space(3)))* lds_u8h_t;
+        const unsigned sink = (unsigned)(size_t)(lds_u8h_t)xs;
+        unsigned seen = 0;                                   // groups whose workgroups sit on this XCD (groups <= 32 here: the host checked)
+        for (int i = xcd; i < r.n_main; i += 8) seen |= 1u << (i % r.groups);
+        for (int k = 0; k < r.helper_convs; ++k) {
+            const RbConv& cv = r.conv[k];
+            const int nlines = MT * cv.ksteps * 16;          // 128-byte lines of one group's fragments of this conv
+            for (int gg = 0; gg < r.groups; ++gg) {
+                if (!((seen >> gg) & 1u)) continue;
+                const unsigned char* wb = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)(gg * MT * cv.ksteps) * 2048u;
+                for (int line = sub * NT + tid; line < nlines; line += r.helpers * NT) {
+                    const unsigned char* ptr = wb + (size_t)line * 128u;
+                    unsigned m0_keep_;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(m0_keep_) : "v"(ptr), "s"(sink) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sink is this workgroup's LDS: nothing may still be landing when it is released
+        return;
+    }
     RB_STAMP(0);
 
     const int g = blockIdx.x % r.groups;
@@ -777,7 +813,8 @@ int rb_go(const RbArgs& r, const RbPlan& pl, hipStream_t s) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)pl.blocks), dim3(256), pl.lds, s, r);
+    const unsigned grid = r.helpers > 0 ? (unsigned)(((r.n_main + 7) & ~7) + 8 * r.helpers) : (unsigned)pl.blocks;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), pl.lds, s, r);
     ADK_HIP_CHECK(hipGetLastError());
     return ADK_OK;
 }
@@ -831,6 +868,30 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
 #if ADK_RB16_DBG & 1
     r.dbg_slot = g_rb_launch++;
 #endif
+    {
+        // helper workgroups (see the kernel head): launches of at most kHelperBlocks computing workgroups; per XCD the weights of the groups it hosts
+        // must fit its L2 beside everything else: the longest prefix of convs within kHelperBytes.  ADK_RB16_HELPERS: helpers per XCD (0 = off).
+        static const int per_xcd = rb_knob("ADK_RB16_HELPERS", 4);
+        static const int max_blocks = rb_knob("ADK_RB16_HELPER_BLOCKS", 64);
+        constexpr long long kHelperBytes = 3584 * 1024;
+        r.n_main = (int)pl.blocks; r.helpers = 0; r.helper_convs = 0;
+        if (per_xcd > 0 && pl.blocks <= max_blocks && a0.groups <= 32) {
+            int worst = 0;                                   // most distinct groups on one XCD
+            for (int x = 0; x < 8; ++x) {
+                unsigned seen = 0; int cnt = 0;
+                for (long long i = x; i < pl.blocks; i += 8) { const unsigned bit = 1u << (int)(i % a0.groups); if (!(seen & bit)) { seen |= bit; ++cnt; } }
+                worst = std::max(worst, cnt);
+            }
+            long long bytes = 0;
+            int kc = 0;
+            for (; kc < n; ++kc) {
+                const long long one = (long long)(pl.C / 32) * r.conv[kc].ksteps * 2048ll * worst;
+                if (bytes + one > kHelperBytes) break;
+                bytes += one;
+            }
+            if (kc > 0 && worst > 0) { r.helpers = per_xcd; r.helper_convs = kc; }
+        }
+    }
     const int act = a0.act_in;
     // Register budgets.  Two n-tiles per wave: 168 registers (three 4-wave workgroups per CU), the residual fetched under the second
     // conv's MFMAs; three: 256 (two workgroups), residual early; four: 256, residual after the loop.  128 channels: 256, prefetch

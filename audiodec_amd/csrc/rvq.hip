@@ -287,6 +287,29 @@ __global__ __launch_bounds__(RVQ_THREADS) void rvq_encode_v3_kernel(const float*
     __shared__ float red_v[RVQ_WAVES];
     __shared__ int red_i[RVQ_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Round 5, few rows: blocks behind the rows are HELPERS (adk_rvq_encode launches 8 * n_help of them behind the rows padded to a multiple of 8).  A row's
+    // workgroup pulls the 2 MB of codes of the 8 stages through ONE CU, from the Infinity Cache (between two frames they have left the L2s): 29 us for a
+    // single row, whatever it computes.  A helper touches one dword of every 128-byte line of the codes and exits: the lines are then in the L2 of ITS XCD,
+    // which -- block b runs on XCD b % 8, an observation, not a contract: a wrong guess costs the speed-up only -- is an XCD that hosts a row.
+    if ((int)blockIdx.x >= n_rows) {
+        const int pad = (n_rows + 7) & ~7;
+        const int h = (int)blockIdx.x - pad;
+        if (h < 0 || (h & 7) >= n_rows) return;              // padding block / an XCD without a row
+        const int n_help = ((int)gridDim.x - pad) >> 3, sub = h >> 3;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(embed);
+        const int nlines = n_q * D * SIZE * 4 / 128;
+        for (int l0 = sub * RVQ_THREADS + tid; l0 < nlines; l0 += 4 * n_help * RVQ_THREADS) {
+            unsigned t0, t1, t2, t3;                           // four lines in flight per thread; the results only have to stay put until they have landed
+            const int st = n_help * RVQ_THREADS;
+            const unsigned char* p0 = base + (size_t)l0 * 128u;
+            const unsigned char* p1 = base + (size_t)min(l0 + st, nlines - 1) * 128u;
+            const unsigned char* p2 = base + (size_t)min(l0 + 2 * st, nlines - 1) * 128u;
+            const unsigned char* p3 = base + (size_t)min(l0 + 3 * st, nlines - 1) * 128u;
+            asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\tglobal_load_dword %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+        }
+        return;
+    }
     const int row = blockIdx.x;
     float r_reg = 0.f, qsum = 0.f;
     float e[D];
@@ -603,7 +626,10 @@ extern "C" int adk_rvq_encode(const float* z, const float* embed, const float* e
     }
     if (variant >= 2 && dim == 64 && size == 1024 && n_rows <= (rb_env > 0 ? rb_env : 256)) {
         if (variant == 3) {
-            hipLaunchKernelGGL(rvq_encode_v3_kernel, dim3(n_rows), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
+            // helper blocks for few rows (see the kernel head; ADK_RVQ_HELPERS per XCD, 0 = none)
+            static const int n_help = [] { const char* e = getenv("ADK_RVQ_HELPERS"); const int v = e ? atoi(e) : 2; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
+            const unsigned grid3 = (n_help > 0 && n_rows <= 64) ? (unsigned)(((n_rows + 7) & ~7) + 8 * n_help) : (unsigned)n_rows;
+            hipLaunchKernelGGL(rvq_encode_v3_kernel, dim3(grid3), dim3(RVQ_THREADS), 0, s, z, embed, enorm,
                                reinterpret_cast<long long*>(idx), zq, n_rows, n_q);
             ADK_HIP_CHECK(hipGetLastError());
             return ADK_OK;
