@@ -1157,16 +1157,20 @@ def main():
                     if pg:
                         pg.exit()
                     torch.cuda.synchronize()
-                    tg = time.perf_counter()
-                    if pg:
-                        pg.enter()
-                    for i in range(ng):
-                        rung(xs[i % n_buf])
-                    if pg:
-                        pg.exit()
-                    torch.cuda.synchronize()
-                    eg = time.perf_counter() - tg
-                    return {"value": round(B * ng * FPS / eg, 1), "unit": "frames/s", "ms_per_step": round(1e3 * eg / ng, 4), "steps": ng}
+                    regions = []
+                    for _ in range(3):                     # three timed regions, the median: a freshly built model sporadically sees one stall of tens of
+                        tg = time.perf_counter()           # milliseconds in its first 100 ms of GPU work (profiles/r2_step_time_outliers.log), which is one of
+                        if pg:                             # these short regions whole
+                            pg.enter()
+                        for i in range(ng):
+                            rung(xs[i % n_buf])
+                        if pg:
+                            pg.exit()
+                        torch.cuda.synchronize()
+                        regions.append(time.perf_counter() - tg)
+                    eg = float(np.median(regions))
+                    return {"value": round(B * ng * FPS / eg, 1), "unit": "frames/s", "ms_per_step": round(1e3 * eg / ng, 4), "steps": ng,
+                            "regions_ms_per_step": [round(1e3 * e_ / ng, 4) for e_ in regions]}
                 out["unguarded"] = timed_pipeline(False, 4)
                 out["unguarded"]["what"] = "AudioDec(guard=False): the same workload and schedule with no per-step check (rounds 1-4 timed this as `value`)"
                 out["guard_synchronous"] = timed_pipeline(True, 0)
