@@ -309,18 +309,38 @@ __global__ __launch_bounds__(256, WPS) void conv_rb16_kernel(RbArgs r) {
         const unsigned sink = (unsigned)(size_t)(lds_u8h_t)xs;
         unsigned seen = 0;                                   // groups whose workgroups sit on this XCD (groups <= 32 here: the host checked)
         for (int i = xcd; i < r.n_main; i += 8) seen |= 1u << (i % r.groups);
+        auto touch = [&](const unsigned char* ptr) __attribute__((always_inline)) {
+            unsigned m0_keep_;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_keep_) : "v"(ptr), "s"(sink) : "memory");
+        };
         for (int k = 0; k < r.helper_convs; ++k) {
+            if (k == 1) {
+                // behind the first conv's weights: the HISTORY rows the later convs fetch from their state rings (rows earlier steps wrote: [cursor - hist,
+                // cursor) of node k, this XCD's streams) -- every one of them is a cold round trip in the computing workgroup's epilogue otherwise
+                for (int i = xcd; i < r.n_main; i += 8) {
+                    const int gi = i % r.groups, s0 = (i / r.groups) * r.spw, sc = min(r.spw, r.batch - s0);
+                    for (int kk = 1; kk < r.n_convs; ++kk) {
+                        const RbNode& nd = r.node[kk];
+                        const int hk = r.conv[kk].hist;
+                        constexpr int LPR = (C * 4 + 127) / 128;
+                        const int total = sc * hk * LPR;
+                        for (int q = sub * NT + tid; q < total; q += r.helpers * NT) {
+                            const int st_ = q / (hk * LPR), rem_ = q - st_ * hk * LPR;
+                            const int rr = rem_ / LPR, li = rem_ - rr * LPR;
+                            int row = nd.cursor - hk + rr;
+                            if (row < 0) row += nd.rows;
+                            touch(reinterpret_cast<const unsigned char*>(nd.base + ((size_t)(s0 + st_) * nd.rows + row) * nd.ch + nd.choff + gi * nd.gstride + 32 * li));
+                        }
+                    }
+                }
+            }
             const RbConv& cv = r.conv[k];
             const int nlines = MT * cv.ksteps * 16;          // 128-byte lines of one group's fragments of this conv
             for (int gg = 0; gg < r.groups; ++gg) {
                 if (!((seen >> gg) & 1u)) continue;
                 const unsigned char* wb = reinterpret_cast<const unsigned char*>(cv.wfrag) + (size_t)(gg * MT * cv.ksteps) * 2048u;
-                for (int line = sub * NT + tid; line < nlines; line += r.helpers * NT) {
-                    const unsigned char* ptr = wb + (size_t)line * 128u;
-                    unsigned m0_keep_;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(m0_keep_) : "v"(ptr), "s"(sink) : "memory");
-                }
+                for (int line = sub * NT + tid; line < nlines; line += r.helpers * NT) touch(wb + (size_t)line * 128u);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sink is this workgroup's LDS: nothing may still be landing when it is released
@@ -907,7 +927,11 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
         return rb_by_taps<32, 3, 1, 2, 1, true, 0, ADK_RB16_RING_SLOTS32>(r, pl, act, s);
     }
     if (pl.C == 64 && pl.wr > 0) return rb_by_taps<64, 2, 1, 3, 1, ADK_RB16_EARLY64, 0, 3>(r, pl, act, s);
+    // (launches of <= 128 workgroups, round 5: no ring -- and no reason to squeeze the two-tile variants into 168 registers for a third workgroup per CU
+    // that never comes: the 256-register builds of the same code have no spills, the 168-register ones 30-33 spilled registers without the ring)
+    const bool few = pl.blocks <= 128;
     if (pl.C == 32) {
+        if (pl.ntw == 2 && few) return rb_by_taps<32, 2, 1, 2, ADK_RB16_PF32, true, 0>(r, pl, act, s);
         if (pl.ntw == 2) return rb_by_taps<32, 2, 1, 3, ADK_RB16_PF32, true, 0>(r, pl, act, s);
         // (three tiles, K11 blocks of the vocoder: with the residual fetched AFTER the second conv's loop the kernel has 1 spilled register
         // instead of 45 -- stage-3 chain 151.6 -> 142.5 us, pipeline +1.2 % on one box; the K7 + 1x1 units of the encoder have no spills
@@ -917,6 +941,7 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
         return rb_by_taps<32, 4, 1, 2, 2, false, 0>(r, pl, act, s);
     }
     if (pl.C == 64) {
+        if (pl.ntw == 2 && pl.spw == 1 && few) return rb_by_taps<64, 2, 1, 2, ADK_RB16_PF64, true, 0>(r, pl, act, s);
         if (pl.ntw == 2 && pl.spw == 1) return rb_by_taps<64, 2, 1, 3, ADK_RB16_PF64, true, 0>(r, pl, act, s);
         if (pl.ntw <= 3) return rb_by_taps<64, 3, 2, 2, 2, true, 0>(r, pl, act, s);
         return rb_by_taps<64, 4, 2, 2, 2, false, 0>(r, pl, act, s);
