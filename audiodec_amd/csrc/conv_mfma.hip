@@ -79,6 +79,7 @@ typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
 constexpr float kSkLoScale = 2048.f, kSkLoInv = 1.f / 2048.f;
 
 constexpr int KC = 64;    // K chunk: two 32-channel half-chunks (each one tap x 32 channels)
+constexpr int kGvCounters = 4096;      // arrival counters of conv_gv16 at the end of the workspace: one per (group, 32-row m-tile) of a launch
 
 struct SkArgs {
     float* ws;            // partial-tile workspace: [G][256 threads][NJ*16] floats
@@ -776,6 +777,153 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
 }
 
 
+// ================================================================================================
+// conv_gv16 -- the split-f16 conv for FEW COLUMNS (n_total <= 32: a handful of streams, layers of 1-25 steps per frame), round 5.
+//
+// One frame of one stream needs every weight once (93 MB for vctk_v1) and multiplies it with a handful of columns: a GEMV.  The stream-K
+// kernel above runs such a conv as 64 x 64 tiles whose K is split over at most five workgroups -- a dozen workgroups on a chip of 256 CUs, each
+// walking 6-9 chunks through LDS staging and barriers, then a partial-tile exchange: 10-17 us per launch whatever the work
+// (profiles/r5_single_stream_latency.md: 23 such launches are 43 % of a single-stream frame).  Here the conv is cut the other way:
+//   * a work item = one 32-row m-tile x one slice of <= MAXS 16-k steps of K, ONE WAVE (64 threads) per item -- hundreds of waves, every CU
+//     pulls a few KiB of weights, all of an item's loads (weights: 2 KiB per step; its 32 columns' operands: 2 x 16 B per lane and step,
+//     straight from the state ring or its shadow) are requested up front, in straight-line code, and consumed in order: one round trip;
+//   * no LDS, no barrier: the B fragment of a lane IS 8 consecutive channels of its column's ring row (activation + split in registers,
+//     or the shadow's [8 hi][8 lo] group as it is);
+//   * the S slices of a tile leave their 32 x 32 partial sums in the workspace (write-through), count in on the tile's counter, and the LAST
+//     one to arrive adds all S in slice order -- a fixed order: the result does not depend on who was last -- and runs the stream-K
+//     kernel's epilogue (bias, residual, output activation, shadow).  Nobody waits for anybody.
+// Per accumulator the order is that of the other split kernels (hi*hi | hi*lo, lo*hi; main + cross / 2048 per slice); where K is cut differs
+// from the stream-K kernel, so results agree with it to f32 round-off, not bit for bit; the same call is bit-reproducible.
+struct GvArgs {
+    float* ws; unsigned ws_bytes;        // partial sums: [item][4 pieces of 16 B][64 lanes]
+    unsigned* counters;                  // [tiles]: slices of the tile that have published; 0 between launches
+    int S;                               // K slices per tile
+    int tiles;                           // groups * mt32_per_g
+    int mt32_per_g;
+    int ksteps, ksteps_packed;           // 16-k steps of K (ktot / 16) / of the packed weights (K padded to 64)
+    int cpt16;                           // 16-k steps per tap = cin_g / 16
+    unsigned in_bytes, w_bytes;
+    float inv_t_out;
+    int* err;
+};
+
+template <int ACT, int MAXS>
+__global__ __launch_bounds__(64) void conv_gv16_kernel(ConvArgs a, GvArgs gv) {
+    const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
+    const int item = blockIdx.x;
+    const int tile = item / gv.S, slice = item - tile * gv.S;
+    if (tile >= gv.tiles) return;
+    const int g = tile / gv.mt32_per_g, mt = tile - g * gv.mt32_per_g;
+    const int s0 = (int)(((long long)slice * gv.ksteps) / gv.S), s1 = (int)(((long long)(slice + 1) * gv.ksteps) / gv.S);
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, gv.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, gv.w_bytes, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // this lane's column (stream b, step t): ring row of tap 0, channel block of its k-half
+    const bool col_ok = l31 < a.n_total;
+    const int nn = col_ok ? l31 : 0;
+    const int b = fast_div(nn, a.t_out, gv.inv_t_out), t = nn - b * a.t_out;
+    const unsigned row_bytes = (unsigned)a.in_ch * 4u, ring_bytes = (unsigned)a.in_rows * row_bytes, dil_bytes = (unsigned)a.dilation * row_bytes;
+    int row0 = a.in_row0 + t * a.stride;
+    if (row0 >= a.in_rows) row0 -= a.in_rows;
+    const unsigned colb = col_ok ? (unsigned)b * ring_bytes + (unsigned)(a.in_choff + g * a.in_gstride + 8 * lh) * 4u : OOB;
+    const unsigned wbase = (unsigned)((g * gv.mt32_per_g + mt) * gv.ksteps_packed) * 2048u;
+    int tap = s0 / gv.cpt16, c16 = s0 - tap * gv.cpt16;
+    unsigned rowb = (unsigned)row0 * row_bytes + (unsigned)tap * dil_bytes;
+    if (rowb >= ring_bytes) rowb -= ring_bytes;
+
+    // ---- every load of the item, up front (steps past the slice's end go out of bounds: zeros, no memory touched) ----
+    u32x4 ah[MAXS], al[MAXS];
+    float4 x0[MAXS], x1[MAXS];
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        const bool ok = s0 + i < s1;
+        const unsigned wo = ok ? wbase + (unsigned)(s0 + i) * 2048u : 0xfff00000u;
+        ah[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16, wo, 0);
+        al[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, lane16 + 1024u, wo, 0);
+        const unsigned vo = (ok && col_ok) ? colb + rowb + (unsigned)c16 * 64u : OOB;
+        x0[i] = buf_load4(rsrc_in, vo, 0);
+        x1[i] = buf_load4(rsrc_in, vo, 16);
+        if (++c16 == gv.cpt16) {
+            c16 = 0;
+            rowb += dil_bytes;
+            if (rowb >= ring_bytes) rowb -= ring_bytes;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // (keep the requests HERE: left alone the scheduler sinks each load to just in front of its use)
+
+    f32x16 acc[1], accx;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; accx[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        union { u32x4 u; f16x8s h; } Ah, Al;
+        Ah.u = ah[i]; Al.u = al[i];
+        f16x8s bh, bl;
+        if constexpr (ACT == kActPre) {
+            union { float4 f; f16x8s h; } c0, c1;
+            c0.f = x0[i]; c1.f = x1[i];
+            bh = c0.h; bl = c1.h;
+        } else {
+            const float x[8] = {x0[i].x, x0[i].y, x0[i].z, x0[i].w, x1[i].x, x1[i].y, x1[i].z, x1[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = act_in_apply<ACT>(x[e], a.slope);
+                const _Float16 h = (_Float16)y;
+                bh[e] = h;
+                bl[e] = (_Float16)((y - (float)h) * kSkLoScale);
+            }
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah.h, bh, acc[0], 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah.h, bl, accx, 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al.h, bh, accx, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][e] = fmaf(accx[e], kSkLoInv, acc[0][e]);
+
+    if (gv.S > 1) {
+        // publish this slice's partial sums (write-through), count in; the last slice to arrive adds all of them in slice order
+        const __amdgpu_buffer_rsrc_t rsrc_ws = __builtin_amdgcn_make_buffer_rsrc(gv.ws, 0, gv.ws_bytes, 0x00020000);
+        const unsigned pbase = (unsigned)item * 4096u + lane16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 v;
+            v.x = __float_as_uint(acc[0][4 * q]); v.y = __float_as_uint(acc[0][4 * q + 1]);
+            v.z = __float_as_uint(acc[0][4 * q + 2]); v.w = __float_as_uint(acc[0][4 * q + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_ws, pbase + (unsigned)q * 1024u, 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(gv.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != (unsigned)(gv.S - 1)) return;
+        if (lane == 0) __hip_atomic_store(gv.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the slices were stored write-through; sc1 loads are served past this CU's L1: no acquire fence -- as the stream-K kernel's owners)
+        u32x4 pv[15][4];
+        const unsigned rb0 = (unsigned)(tile * gv.S) * 4096u + lane16;
+#pragma unroll
+        for (int sl = 0; sl < 15; ++sl) {
+            const unsigned ro = sl < gv.S ? rb0 + (unsigned)sl * 4096u : OOB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pv[sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ws, ro, (unsigned)q * 1024u, 16 /* sc1 */);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][e] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 15; ++sl) {
+            if (sl < gv.S) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[0][4 * q] += __uint_as_float(pv[sl][q].x); acc[0][4 * q + 1] += __uint_as_float(pv[sl][q].y);
+                    acc[0][4 * q + 2] += __uint_as_float(pv[sl][q].z); acc[0][4 * q + 3] += __uint_as_float(pv[sl][q].w);
+                }
+            }
+        }
+    }
+    sk_epilogue<1, true>(a, acc, g, mt * 32, 0, lane, gv.err);
+}
+
+
 // fragment packing: w [groups*cout_g][ktot] row-major -> [g][m-tile32][k-group8][lane64][4]
 // lane (i = lane&31, h = lane>>5) holds W[32*mt + i][8*kg + 4*h + 0..3]; rows >= cout_g and the K
 // tail (K is padded to a multiple of 64) are zero.
@@ -988,7 +1136,8 @@ size_t conv_mfma_workspace_bytes(size_t* flags_offset) {
     }
     const size_t part = (size_t)256 * g_occ * 256 * 4 * 16 * sizeof(float);
     if (flags_offset) *flags_offset = part;
-    return part + (size_t)2 * 256 * g_occ * sizeof(unsigned);       // flags for up to twice the resident workgroups (oversubscribed plans)
+    return part + (size_t)2 * 256 * g_occ * sizeof(unsigned)        // flags for up to twice the resident workgroups (oversubscribed plans)
+           + (size_t)kGvCounters * sizeof(unsigned);                // ... and the per-tile arrival counters of conv_gv16 (zero between launches)
 }
 
 int conv_mfma_pick(const ConvArgs& a) {
@@ -1029,9 +1178,57 @@ int conv_sk16_pick(const ConvArgs& a) {
 }
 
 
+// ---- conv_gv16 host side ----
+static int g_gv = -1;          // ADK_GV16: 1 (default) = convs of at most 32 columns run as conv_gv16, 0 = never (the stream-K kernel takes them)
+bool conv_gv16_preferred(const ConvArgs& a) {
+    if (g_gv < 0) { const char* e = getenv("ADK_GV16"); g_gv = e ? atoi(e) : 1; }
+    if (!g_gv || !conv_mfma_supported(a) || a.n_total < 1 || a.n_total > 32 || a.ktot % 16) return false;
+    const long long steps = a.ktot / 16;
+    const long long tiles = (long long)a.groups * ((a.cout_g + 31) / 32);
+    if (steps > 15 * 24 || tiles > kGvCounters) return false;                 // at most 15 slices of at most 24 steps
+    const long long S = steps <= 12 * 15 ? (steps + 11) / 12 : (steps + 23) / 24;
+    return tiles * S * 4096ll <= 0x7fffffffll && tiles * S <= 65535 * 8;
+}
+
+int launch_conv_gv16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
+    GvArgs gv;
+    gv.mt32_per_g = (a.cout_g + 31) / 32;
+    gv.tiles = a.groups * gv.mt32_per_g;
+    gv.ksteps = a.ktot / 16;
+    gv.ksteps_packed = (a.ktot + 63) / 64 * 4;
+    gv.cpt16 = a.cin_g / 16;
+    const bool small = gv.ksteps <= 12 * 15;
+    gv.S = small ? (gv.ksteps + 11) / 12 : (gv.ksteps + 23) / 24;
+    gv.inv_t_out = 1.0f / (float)a.t_out;
+    gv.in_bytes = (unsigned)((unsigned long long)a.batch * a.in_rows * a.in_ch * 4ull);
+    gv.w_bytes = (unsigned)((unsigned long long)a.groups * gv.mt32_per_g * gv.ksteps_packed * 2048ull);
+    size_t flags_offset = 0;
+    const size_t need = conv_mfma_workspace_bytes(&flags_offset);
+    const size_t part = (size_t)gv.tiles * gv.S * 4096;
+    if (!ws.ptr || ws.bytes < need || part > flags_offset) return fail(ADK_ERR_STATE, "conv_gv16: workspace missing or too small");
+    gv.ws = ws.ptr; gv.ws_bytes = (unsigned)part;
+    gv.counters = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws.ptr) + need - (size_t)kGvCounters * sizeof(unsigned));
+    gv.err = conv_err_word(a);
+    const unsigned grid = (unsigned)(gv.tiles * gv.S);
+    ConvArgs b = a;
+    int act = a.act_in;
+    if (a.in_sh) { b.in = a.in_sh; act = kActPre; }
+#define ADK_GV_LAUNCH(ACT_) do { if (small) hipLaunchKernelGGL((conv_gv16_kernel<ACT_, 12>), dim3(grid), dim3(64), 0, s, b, gv); \
+                                 else hipLaunchKernelGGL((conv_gv16_kernel<ACT_, 24>), dim3(grid), dim3(64), 0, s, b, gv); } while (0)
+    if (act == kActPre) ADK_GV_LAUNCH(kActPre);
+    else if (act == ADK_ACT_ELU) ADK_GV_LAUNCH(ADK_ACT_ELU);
+    else if (act == ADK_ACT_LEAKY) ADK_GV_LAUNCH(ADK_ACT_LEAKY);
+    else if (act == ADK_ACT_NONE) ADK_GV_LAUNCH(ADK_ACT_NONE);
+    else return fail(ADK_ERR_ARG, "conv: unsupported input activation for the MFMA kernel");
+#undef ADK_GV_LAUNCH
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     if (a.n_total == 0) return ADK_OK;
     (void)conv_mfma_workspace_bytes(nullptr);
+    if (conv_gv16_preferred(a)) return launch_conv_gv16(a, s, ws);
     // ADK_SK16_KD=2: 128-deep chunks.  Measured: single launches of the small layers 20-30 % faster (transposed convs
     // 26.6 -> 18.8 us), single-stream latency 1.09 -> 1.03 ms, but 67.6 KB of LDS per workgroup keeps concurrently
     // running programs off the CU: 3-stream pipeline 196 k vs 204 k frames/s.  Default 64-deep.

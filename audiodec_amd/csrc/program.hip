@@ -138,6 +138,7 @@ static std::string conv_kernel_name(const ConvArgs& a, int impl) {
         if (impl == ADK_IMPL_SPLIT16_UP || (impl == ADK_IMPL_SPLIT16 && g_use_up && conv_up16_supported(a))) return "conv_up16<64>";
         const bool rows = impl == ADK_IMPL_SPLIT16_ROWS || (impl == ADK_IMPL_SPLIT16 && g_use_rl && conv_rl16_preferred(a));
         if (rows) return a.cin_g == 32 ? "conv_rl16<32>" : "conv_rl16<64>";
+        if (conv_gv16_preferred(a)) return "conv_gv16<32>";
         return std::string(conv_mfma_cfg_name(conv_sk16_pick(a))).replace(0, 7, "conv_sk16");
     }
     const bool mf = impl != ADK_IMPL_DIRECT && conv_mfma_supported(a) && (impl == ADK_IMPL_MFMA || impl == ADK_IMPL_MFMA_ROWS || a.groups * a.cout_g >= 32);

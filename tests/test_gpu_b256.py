@@ -480,7 +480,7 @@ def test_shadow_rings_are_bit_identical(gpu, ckpt_root, monkeypatch, model, B, m
     for pr in progs:
         for i in range(pr.n_ops):
             if pr._ops[i].out_shadow:
-                assert pr.describe_op(i, 1).startswith("conv_sk16<"), (pr.op_names[i], pr.describe_op(i, 1))
+                assert pr.describe_op(i, 1).startswith(("conv_sk16<", "conv_gv16<")), (pr.op_names[i], pr.describe_op(i, 1))      # (few columns: the GEMV-shaped kernel, same epilogue)
     monkeypatch.setattr(program, "SHADOW_RINGS", False)
     ad0 = load_audiodec(ckpt_root, model, seed, B, max_frames, True)
     progs0 = [ad0.tx_encoder._encoder()] + (list(ad0.decoder._decoder_stages()) if hasattr(ad0.decoder, "_decoder_stages") else [ad0.decoder._decoder()])

@@ -176,6 +176,72 @@ def test_streamk_schedules_agree_with_direct_kernel(gpu, cin, cout, k, s, d, gr,
     assert native.device_flags() == 0
 
 
+@pytest.mark.parametrize("cin,cout,k,s,d,gr,act,B,L,what", [
+    (256, 256, 7, 1, 9, 1, "ELU", 1, 5, "encoder block 3 at one stream: 8 m-tiles x 10 slices"),
+    (768, 768, 11, 1, 5, 3, "LeakyReLU", 1, 5, "vocoder stage 0 at one stream: 24 tiles x 15 slices of 11-12 steps"),
+    (768, 768, 11, 1, 5, 3, "LeakyReLU", 6, 5, "... six streams: 30 of 32 columns"),
+    (512, 64, 3, 1, 1, 1, None, 32, 1, "projector at 32 streams: 2 tiles, full 32 columns"),
+    (256, 512, 10, 5, 1, 1, None, 3, 2, "strided conv (K10, stride 5): ring rows 5 apart per column"),
+    (64, 512, 7, 1, 1, 1, None, 2, 1, "input conv: 28 steps, 3 slices"),
+    (384, 128, 1, 1, 1, 1, None, 1, 25, "1x1 conv_out: 24 steps, 2 slices"),
+    (96, 96, 3, 1, 1, 3, "LeakyReLU", 7, 4, "cout_g = 32, 6 steps: ONE slice, no exchange"),
+    (1024, 128, 7, 1, 3, 1, "ELU", 2, 9, "448 steps: beyond 15 x 24 -> stays on the stream-K kernel"),
+    (160, 96, 3, 1, 2, 1, "ELU", 4, 8, "cout_g = 96 (three m-tiles), 30 steps: slices of 10"),
+])
+def test_few_column_kernel_agrees_with_direct_kernel_and_oracle(gpu, cin, cout, k, s, d, gr, act, B, L, what):
+    """conv_gv16 (csrc/conv_mfma.hip, round 5): convs of at most 32 columns run as one wave per (32-row m-tile, K slice) with the slices'
+    partial sums added by the last one to arrive.  Against the scalar direct kernel and the oracle (CausalConv1d.inference,
+    layers/conv_layer.py:153-156) over calls that wrap the ring, twice (bit-reproducible: the slices are added in slice order)."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(cin + 13 * k + B)
+    w = torch.randn(cout, cin // gr, k, generator=g) / (cin // gr * k) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    fn = {None: lambda v: v, "ELU": torch.nn.ELU(), "LeakyReLU": torch.nn.LeakyReLU(0.1)}[act]
+    mods = {}
+    for key, impl in (("direct", native.IMPL_DIRECT), ("gv", native.IMPL_SPLIT16_SK), ("gv2", native.IMPL_SPLIT16_SK)):
+        m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
+        m.set_activation(act, 0.1)
+        m.impl = impl
+        mods[key] = m
+    pad = torch.zeros(B, cin, (k - 1) * d)
+    for step in range(4):
+        x = torch.randn(B, cin, L * s, generator=g)
+        ref, pad = O.causal_conv1d_inference(fn(x), fn(pad) if step == 0 else pad, w, bias, s, d, gr)
+        yd = mods["direct"].inference(x.to(gpu))
+        y1 = mods["gv"].inference(x.to(gpu))
+        y2 = mods["gv2"].inference(x.to(gpu))
+        want = "conv_sk16" if cin // gr * k // 16 > 360 else "conv_gv16<32>"
+        assert mods["gv"].last_kernel.startswith(want), (what, mods["gv"].last_kernel)
+        assert float((y1 - yd).abs().max()) < 2e-5 and float((y1.cpu() - ref).abs().max()) < 2e-5, (what, step)
+        assert torch.equal(y1, y2), (what, step)
+    assert native.device_flags() == 0
+
+
+@pytest.mark.parametrize("cin,cout,stride,B,L", [(512, 256, 5, 1, 1), (256, 128, 5, 2, 5), (128, 64, 4, 1, 25), (64, 32, 3, 3, 10)])
+def test_few_column_kernel_transposed_convs(gpu, cin, cout, stride, B, L):
+    """The polyphase form of CausalConvTranspose1d.inference (layers/conv_layer.py:194-197: K = 2 * stride, two taps, stride * Cout GEMM rows
+    written as `stride` ring rows per input step) through conv_gv16: upsamples.0 ... 3 of the vocoder at one to three streams."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(cin + stride)
+    w = torch.randn(cin, cout, 2 * stride, generator=g) / (2 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    mods = {}
+    for key, impl in (("direct", native.IMPL_DIRECT), ("gv", native.IMPL_SPLIT16_SK)):
+        m = layers.CausalConvTranspose1d(cin, cout, 2 * stride, stride, True, device=gpu, batch=B, max_len=L).load(w, bias)
+        m.set_activation("LeakyReLU", 0.1)
+        m.impl = impl
+        mods[key] = m
+    pad = torch.zeros(B, cin, 1)
+    lrelu = torch.nn.LeakyReLU(0.1)
+    for step in range(4):
+        x = torch.randn(B, cin, L, generator=g)
+        ref, pad = O.causal_convtr1d_inference(lrelu(x), lrelu(pad) if step == 0 else pad, w, bias, stride)
+        yd, y1 = mods["direct"].inference(x.to(gpu)), mods["gv"].inference(x.to(gpu))
+        assert mods["gv"].last_kernel == ("conv_gv16<32>" if B * L <= 32 else mods["gv"].last_kernel)
+        assert float((y1 - yd).abs().max()) < 2e-5 and float((y1.cpu() - ref).abs().max()) < 2e-5, step
+    assert native.device_flags() == 0
+
+
 def test_elu_of_the_kernels_against_fp64(gpu):
     """The kernels' own ELU (expm1_neg, csrc/adk_common.h) through an identity 1x1 conv on the exact-f32 kernels: relative error
     against torch's fp64 ELU <= 4e-7 over [-20, 2] (the reference applies torch.nn.ELU in fp32: layers/activation_function.py:18-22)."""
@@ -335,7 +401,7 @@ def test_pipeline_matches_reference_fixture(gpu, golden_dir, ckpt_root, name, ma
         ad = load_audiodec(ckpt_root, model, seed, n, max_frames, split16)
         if split16:                                              # the split kernels really are in the programs
             kinds = [ad.decoder._decoder().describe_op(i, 1) for i in range(ad.decoder._decoder().n_ops)]
-            assert any(k.startswith("conv_rl16") or k.startswith("conv_sk16") for k in kinds), kinds
+            assert any(k.startswith(("conv_rl16", "conv_sk16", "conv_gv16")) for k in kinds), kinds
             assert "noaddl" in model or any(k.startswith("conv_rb16") for k in kinds), kinds     # (x + convs1(act(x)) blocks have no chain)
         z, idx, zq, y = run_hip(ad, audio, chunks)
     finally:
