@@ -96,6 +96,7 @@ int launch_conv_up16(const ConvArgs& a, hipStream_t s);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)
 int conv_sk16_pick(const ConvArgs& a);
 bool conv_gv16_preferred(const ConvArgs& a);        // few columns (n_total <= 32): the GEMV-shaped kernel launch_conv_sk16 hands them to
+int conv_set_option(const char* name, int value);  // conv_mfma.hip: 0 = set, 1 = not a conv option
 int rvq_set_option(const char* name, int value);   // rvq.hip: 0 = set, 1 = not an RVQ option, -1 = bad value
 int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int ktot, hipStream_t s);
 int* flags_word();                                   // address of the sticky debug/error flags ON THE CURRENT DEVICE

@@ -46,6 +46,7 @@
 // error analysis.
 #include "adk_common.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #ifndef ADK_SK_SC1_READ
@@ -778,13 +779,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
 
 
 // ================================================================================================
-// conv_gv16 -- the split-f16 conv for FEW COLUMNS (n_total <= 32: a handful of streams, layers of 1-25 steps per frame), round 5.
+// conv_gv16 -- the split-f16 conv for FEW COLUMNS (a handful of streams, layers of 1-25 steps per frame; by default n_total <= 32, option
+// "gv16_max_columns"), round 5.
 //
 // One frame of one stream needs every weight once (93 MB for vctk_v1) and multiplies it with a handful of columns: a GEMV.  The stream-K
 // kernel above runs such a conv as 64 x 64 tiles whose K is split over at most five workgroups -- a dozen workgroups on a chip of 256 CUs, each
 // walking 6-9 chunks through LDS staging and barriers, then a partial-tile exchange: 10-17 us per launch whatever the work
 // (profiles/r5_single_stream_latency.md: 23 such launches are 43 % of a single-stream frame).  Here the conv is cut the other way:
-//   * a work item = one 32-row m-tile x one slice of <= MAXS 16-k steps of K, ONE WAVE (64 threads) per item -- hundreds of waves, every CU
+//   * a work item = one 32-row m-tile x one 32-column n-tile x one slice of <= MAXS 16-k steps of K, ONE WAVE (64 threads) per item -- hundreds of waves, every CU
 //     pulls a few KiB of weights, all of an item's loads (weights: 2 KiB per step; its 32 columns' operands: 2 x 16 B per lane and step,
 //     straight from the state ring or its shadow) are requested up front, in straight-line code, and consumed in order: one round trip;
 //   * no LDS, no barrier: the B fragment of a lane IS 8 consecutive channels of its column's ring row (activation + split in registers,
@@ -796,9 +798,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
 // from the stream-K kernel, so results agree with it to f32 round-off, not bit for bit; the same call is bit-reproducible.
 struct GvArgs {
     float* ws; unsigned ws_bytes;        // partial sums: [item][4 pieces of 16 B][64 lanes]
-    unsigned* counters;                  // [tiles]: slices of the tile that have published; 0 between launches
+    unsigned* counters;                  // [tiles][ntiles]: slices of the tile that have published; 0 between launches
     int S;                               // K slices per tile
     int tiles;                           // groups * mt32_per_g
+    int ntiles;                          // 32-column tiles: (n_total + 31) / 32
     int mt32_per_g;
     int ksteps, ksteps_packed;           // 16-k steps of K (ktot / 16) / of the packed weights (K padded to 64)
     int cpt16;                           // 16-k steps per tap = cin_g / 16
@@ -811,7 +814,8 @@ template <int ACT, int MAXS>
 __global__ __launch_bounds__(64) void conv_gv16_kernel(ConvArgs a, GvArgs gv) {
     const int lane = threadIdx.x, l31 = lane & 31, lh = lane >> 5;
     const int item = blockIdx.x;
-    const int tile = item / gv.S, slice = item - tile * gv.S;
+    const int otile = item / gv.S, slice = item - otile * gv.S;          // otile = (m-tile, n-tile): slices of one output tile are neighbours
+    const int tile = otile / gv.ntiles, nt = otile - tile * gv.ntiles;
     if (tile >= gv.tiles) return;
     const int g = tile / gv.mt32_per_g, mt = tile - g * gv.mt32_per_g;
     const int s0 = (int)(((long long)slice * gv.ksteps) / gv.S), s1 = (int)(((long long)(slice + 1) * gv.ksteps) / gv.S);
@@ -820,8 +824,8 @@ __global__ __launch_bounds__(64) void conv_gv16_kernel(ConvArgs a, GvArgs gv) {
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, gv.w_bytes, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     // this lane's column (stream b, step t): ring row of tap 0, channel block of its k-half
-    const bool col_ok = l31 < a.n_total;
-    const int nn = col_ok ? l31 : 0;
+    const bool col_ok = nt * 32 + l31 < a.n_total;
+    const int nn = col_ok ? nt * 32 + l31 : 0;
     const int b = fast_div(nn, a.t_out, gv.inv_t_out), t = nn - b * a.t_out;
     const unsigned row_bytes = (unsigned)a.in_ch * 4u, ring_bytes = (unsigned)a.in_rows * row_bytes, dil_bytes = (unsigned)a.dilation * row_bytes;
     int row0 = a.in_row0 + t * a.stride;
@@ -894,13 +898,13 @@ __global__ __launch_bounds__(64) void conv_gv16_kernel(ConvArgs a, GvArgs gv) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(gv.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) old = __hip_atomic_fetch_add(gv.counters + otile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = __builtin_amdgcn_readfirstlane(old);
         if (old != (unsigned)(gv.S - 1)) return;
-        if (lane == 0) __hip_atomic_store(gv.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(gv.counters + otile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (the slices were stored write-through; sc1 loads are served past this CU's L1: no acquire fence -- as the stream-K kernel's owners)
         u32x4 pv[15][4];
-        const unsigned rb0 = (unsigned)(tile * gv.S) * 4096u + lane16;
+        const unsigned rb0 = (unsigned)(otile * gv.S) * 4096u + lane16;
 #pragma unroll
         for (int sl = 0; sl < 15; ++sl) {
             const unsigned ro = sl < gv.S ? rb0 + (unsigned)sl * 4096u : OOB;
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(64) void conv_gv16_kernel(ConvArgs a, GvArgs gv) {
             }
         }
     }
-    sk_epilogue<1, true>(a, acc, g, mt * 32, 0, lane, gv.err);
+    sk_epilogue<1, true>(a, acc, g, mt * 32, nt * 32, lane, gv.err);
 }
 
 
@@ -1179,21 +1183,38 @@ int conv_sk16_pick(const ConvArgs& a) {
 
 
 // ---- conv_gv16 host side ----
-static int g_gv = -1;          // ADK_GV16: 1 (default) = convs of at most 32 columns run as conv_gv16, 0 = never (the stream-K kernel takes them)
+static int g_gv = -1;          // ADK_GV16: 1 (default) = convs of few columns run as conv_gv16, 0 = never (the stream-K kernel takes them)
+static int g_gv_maxn = -1;     // ... "few" = at most this many columns (ADK_GV16_MAXN / option "gv16_max_columns"; default 32 = one n-tile)
+static void gv_read_env() {
+    if (g_gv < 0) {
+        const char* e = getenv("ADK_GV16"); g_gv = e ? atoi(e) : 1;
+        e = getenv("ADK_GV16_MAXN"); g_gv_maxn = e ? atoi(e) : 32;
+        if (g_gv_maxn < 0) g_gv_maxn = 0;
+    }
+}
+int conv_set_option(const char* name, int value) {
+    if (strcmp(name, "gv16_max_columns")) return 1;
+    gv_read_env();
+    g_gv_maxn = value < 0 ? 0 : value;
+    return 0;
+}
 bool conv_gv16_preferred(const ConvArgs& a) {
-    if (g_gv < 0) { const char* e = getenv("ADK_GV16"); g_gv = e ? atoi(e) : 1; }
-    if (!g_gv || !conv_mfma_supported(a) || a.n_total < 1 || a.n_total > 32 || a.ktot % 16) return false;
+    gv_read_env();
+    if (!g_gv || !conv_mfma_supported(a) || a.n_total < 1 || a.n_total > g_gv_maxn || a.ktot % 16) return false;
     const long long steps = a.ktot / 16;
-    const long long tiles = (long long)a.groups * ((a.cout_g + 31) / 32);
-    if (steps > 15 * 24 || tiles > kGvCounters) return false;                 // at most 15 slices of at most 24 steps
+    const long long otiles = (long long)a.groups * ((a.cout_g + 31) / 32) * ((a.n_total + 31) / 32);
+    if (steps > 15 * 24 || otiles > kGvCounters) return false;                // at most 15 slices of at most 24 steps
     const long long S = steps <= 12 * 15 ? (steps + 11) / 12 : (steps + 23) / 24;
-    return tiles * S * 4096ll <= 0x7fffffffll && tiles * S <= 65535 * 8;
+    size_t part = 0;
+    (void)conv_mfma_workspace_bytes(&part);
+    return otiles * S * 4096ll <= (long long)part && otiles * S <= 65535 * 8;  // the slices' partial sums fit the workspace
 }
 
 int launch_conv_gv16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     GvArgs gv;
     gv.mt32_per_g = (a.cout_g + 31) / 32;
     gv.tiles = a.groups * gv.mt32_per_g;
+    gv.ntiles = (a.n_total + 31) / 32;
     gv.ksteps = a.ktot / 16;
     gv.ksteps_packed = (a.ktot + 63) / 64 * 4;
     gv.cpt16 = a.cin_g / 16;
@@ -1204,12 +1225,12 @@ int launch_conv_gv16(const ConvArgs& a, hipStream_t s, Workspace& ws) {
     gv.w_bytes = (unsigned)((unsigned long long)a.groups * gv.mt32_per_g * gv.ksteps_packed * 2048ull);
     size_t flags_offset = 0;
     const size_t need = conv_mfma_workspace_bytes(&flags_offset);
-    const size_t part = (size_t)gv.tiles * gv.S * 4096;
+    const size_t part = (size_t)gv.tiles * gv.ntiles * gv.S * 4096;
     if (!ws.ptr || ws.bytes < need || part > flags_offset) return fail(ADK_ERR_STATE, "conv_gv16: workspace missing or too small");
     gv.ws = ws.ptr; gv.ws_bytes = (unsigned)part;
     gv.counters = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws.ptr) + need - (size_t)kGvCounters * sizeof(unsigned));
     gv.err = conv_err_word(a);
-    const unsigned grid = (unsigned)(gv.tiles * gv.S);
+    const unsigned grid = (unsigned)(gv.tiles * gv.ntiles * gv.S);
     ConvArgs b = a;
     int act = a.act_in;
     if (a.in_sh) { b.in = a.in_sh; act = kActPre; }

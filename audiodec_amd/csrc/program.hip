@@ -161,6 +161,7 @@ extern "C" int adk_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_blocks")) { g_chain_min_blocks = value < 0 ? 0 : value; return ADK_OK; }
+    if (conv_set_option(name, value) == 0) return ADK_OK;
     {
         const int r = rvq_set_option(name, value);
         if (r == 0) return ADK_OK;

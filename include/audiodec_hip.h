@@ -82,6 +82,9 @@ int adk_set_conv_cfg(int32_t cfg);
  *                         "rvq_v4_min" rows (default 192) on, 2 or 4 rows share a workgroup's code registers; 1 (default) = 2 up to 512
  *                         rows, 4 above; 0: the round-3 kernels at every row count.  Indices and zq are bit-identical either way.
  *   "rvq_v4_min"          see above
+ *   "gv16_max_columns"    convs of at most this many columns (streams x steps per call) run as conv_gv16 (csrc/conv_mfma.hip: one wave per
+ *                         32-row x 32-column output tile and K slice, no LDS) instead of the stream-K kernel; default 32, 0 = never
+ *                         (also env ADK_GV16_MAXN).  Results of the two kernels agree to f32 round-off, not bit for bit.
  * ADK_ERR_ARG for an unknown name. */
 int adk_set_option(const char* name, int32_t value);
 /* Introspection of the stream-K launch schedule (pure host logic, no device needed; used by the CPU tests): a matrix-core conv

@@ -217,6 +217,44 @@ def test_few_column_kernel_agrees_with_direct_kernel_and_oracle(gpu, cin, cout, 
     assert native.device_flags() == 0
 
 
+@pytest.mark.parametrize("cin,cout,k,s,d,gr,act,B,L,what", [
+    (512, 64, 3, 1, 1, 1, None, 256, 1, "projector at 256 streams: 2 m-tiles x 8 n-tiles x 8 slices"),
+    (256, 256, 7, 1, 9, 1, "ELU", 40, 5, "encoder block 3, 200 columns: the last n-tile is ragged (8 of 32)"),
+    (256, 512, 10, 5, 1, 1, None, 100, 1, "strided conv at 100 streams"),
+    (768, 768, 11, 1, 5, 3, "LeakyReLU", 13, 5, "vocoder stage 0, 65 columns: 24 x 3 x 15 slices = 1080 waves; one column in the last n-tile"),
+    (768, 768, 11, 1, 5, 3, "LeakyReLU", 52, 5, "... 260 columns: beyond the option's limit -> the stream-K kernel"),
+])
+def test_few_column_kernel_over_several_column_tiles(gpu, cin, cout, k, s, d, gr, act, B, L, what):
+    """conv_gv16 with option "gv16_max_columns" = 256: one wave per (m-tile, 32-column n-tile, K slice), one arrival counter per output tile.
+    Same checks as above (direct kernel, oracle, bit-reproducible), over ring wrap-around."""
+    from audiodec_amd import layers, native
+    g = torch.Generator().manual_seed(cin + 13 * k + B)
+    w = torch.randn(cout, cin // gr, k, generator=g) / (cin // gr * k) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    fn = {None: lambda v: v, "ELU": torch.nn.ELU(), "LeakyReLU": torch.nn.LeakyReLU(0.1)}[act]
+    native.set_option("gv16_max_columns", 256)
+    try:
+        mods = {}
+        for key, impl in (("direct", native.IMPL_DIRECT), ("gv", native.IMPL_SPLIT16_SK), ("gv2", native.IMPL_SPLIT16_SK)):
+            m = layers.CausalConv1d(cin, cout, k, s, d, gr, True, device=gpu, batch=B, max_len=L * s).load(w, bias)
+            m.set_activation(act, 0.1)
+            m.impl = impl
+            mods[key] = m
+        pad = torch.zeros(B, cin, (k - 1) * d)
+        for step in range(4):
+            x = torch.randn(B, cin, L * s, generator=g)
+            ref, pad = O.causal_conv1d_inference(fn(x), fn(pad) if step == 0 else pad, w, bias, s, d, gr)
+            yd = mods["direct"].inference(x.to(gpu))
+            y1 = mods["gv"].inference(x.to(gpu))
+            y2 = mods["gv2"].inference(x.to(gpu))
+            assert mods["gv"].last_kernel.startswith("conv_gv16<32>" if B * L <= 256 else "conv_sk16"), (what, mods["gv"].last_kernel)
+            assert float((y1 - yd).abs().max()) < 2e-5 and float((y1.cpu() - ref).abs().max()) < 2e-5, (what, step)
+            assert torch.equal(y1, y2), (what, step)
+        assert native.device_flags() == 0
+    finally:
+        native.set_option("gv16_max_columns", 32)
+
+
 @pytest.mark.parametrize("cin,cout,stride,B,L", [(512, 256, 5, 1, 1), (256, 128, 5, 2, 5), (128, 64, 4, 1, 25), (64, 32, 3, 3, 10)])
 def test_few_column_kernel_transposed_convs(gpu, cin, cout, stride, B, L):
     """The polyphase form of CausalConvTranspose1d.inference (layers/conv_layer.py:194-197: K = 2 * stride, two taps, stride * Cout GEMM rows
