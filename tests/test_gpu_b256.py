@@ -163,12 +163,17 @@ def test_deep_grouped_convs_match_oracle(gpu, d, with_res, C_, T, B, impl_name, 
 
 
 @pytest.mark.parametrize("cout,s,act,B,chunks", [(32, 3, "LeakyReLU", 9, [100, 100, 37, 100]), (32, 3, None, 3, [300, 5, 129]),
-                                                 (16, 2, "ELU", 4, [64, 1, 200]), (24, 4, "LeakyReLU", 2, [50, 50])])
+                                                 (16, 2, "ELU", 4, [64, 1, 200]), (24, 4, "LeakyReLU", 2, [50, 50]),
+                                                 # >= 1024 chunks of 128 steps: two chunks per workgroup, the second prefetched (TPW = 2)
+                                                 (32, 3, "LeakyReLU", 256, [500, 500, 389]),       # 5 frames per call at 256 streams; 4 chunks, the last ragged
+                                                 (32, 3, "ELU", 8, [16500, 300, 16434]),           # 129 chunks per stream: the last pair has ONE chunk
+                                                 (16, 2, None, 41, [3200, 3137])])                 # two m-tiles, 25 chunks x 41 streams = 1025
 def test_upsampling_streamer_matches_oracle(gpu, cout, s, act, B, chunks):
     """conv_up16 (the north-star's named kernel: fused activation -> ConvTranspose1d(64 -> cout, K = 2s, stride s) + bias,
     models/vocoder/HiFiGAN.py:285-289, layers/conv_layer.py:194-197): chunk lengths that are not multiples of the 32-step
     tile, longer than one 128-step workgroup, one step, ring wrap-around; with and without the input activation (the
-    symmetric decoder has none); also against the rows-in-LDS and stream-K kernels it replaces for this layer."""
+    symmetric decoder has none); also against the rows-in-LDS and stream-K kernels it replaces for this layer.  Launches of at least
+    1024 chunks run two chunks per workgroup (second chunk's loads under the first chunk's MFMAs): even, odd and ragged chunk counts."""
     from audiodec_amd import layers, native
     from oracle import audiodec_oracle as O
     g = torch.Generator().manual_seed(31 * cout + s)
