@@ -14,4 +14,4 @@ bash tools/gpu_session.sh $tag bench
 ( timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_20_steps.json 2> gpurun_out/${tag}_bench_20_steps.err ); echo "bench20 rc=$?"
 python tools/rb16_trace.py 256 1 2>&1 | grep -v "^Load\|amdgpu.ids" > gpurun_out/${tag}_rb16_trace.log; echo "trace rc=$?"
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/${tag}_smoke.log 2>&1 ); echo "smoke rc=$?"; tail -n 2 gpurun_out/${tag}_smoke.log
-bash tools/gpu_session.sh $tag tests
+[ "${ADK_FINAL_SKIP_TESTS:-0}" = 1 ] || bash tools/gpu_session.sh $tag tests     # (a re-capture of an already tested build on another box skips the suite)
