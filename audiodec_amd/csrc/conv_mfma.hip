@@ -48,6 +48,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <atomic>
+#include <mutex>
 
 #ifndef ADK_SK_SC1_READ
 #define ADK_SK_SC1_READ 1   // 1: partial tiles read with sc1 loads, no acquire fence; 0: plain loads behind an agent-scope acquire
@@ -1183,24 +1185,25 @@ int conv_sk16_pick(const ConvArgs& a) {
 
 
 // ---- conv_gv16 host side ----
-static int g_gv = -1;          // ADK_GV16: 1 (default) = convs of few columns run as conv_gv16, 0 = never (the stream-K kernel takes them)
-static int g_gv_maxn = -1;     // ... "few" = at most this many columns (ADK_GV16_MAXN / option "gv16_max_columns"; default 32 = one n-tile)
+// (atomics + one call_once env read, as for the RVQ options: adk_set_option may be called from another host thread than the one launching)
+static std::atomic<int> g_gv{1};         // ADK_GV16: 1 (default) = convs of few columns run as conv_gv16, 0 = never (the stream-K kernel takes them)
+static std::atomic<int> g_gv_maxn{32};   // ... "few" = at most this many columns (ADK_GV16_MAXN / option "gv16_max_columns"; default 32 = one n-tile)
+static std::once_flag g_gv_once;
 static void gv_read_env() {
-    if (g_gv < 0) {
-        const char* e = getenv("ADK_GV16"); g_gv = e ? atoi(e) : 1;
-        e = getenv("ADK_GV16_MAXN"); g_gv_maxn = e ? atoi(e) : 32;
-        if (g_gv_maxn < 0) g_gv_maxn = 0;
-    }
+    std::call_once(g_gv_once, [] {
+        const char* e = getenv("ADK_GV16"); if (e) g_gv.store(atoi(e));
+        e = getenv("ADK_GV16_MAXN"); if (e) g_gv_maxn.store(atoi(e) < 0 ? 0 : atoi(e));
+    });
 }
 int conv_set_option(const char* name, int value) {
     if (strcmp(name, "gv16_max_columns")) return 1;
     gv_read_env();
-    g_gv_maxn = value < 0 ? 0 : value;
+    g_gv_maxn.store(value < 0 ? 0 : value);
     return 0;
 }
 bool conv_gv16_preferred(const ConvArgs& a) {
     gv_read_env();
-    if (!g_gv || !conv_mfma_supported(a) || a.n_total < 1 || a.n_total > g_gv_maxn || a.ktot % 16) return false;
+    if (!g_gv.load() || !conv_mfma_supported(a) || a.n_total < 1 || a.n_total > g_gv_maxn.load() || a.ktot % 16) return false;
     const long long steps = a.ktot / 16;
     const long long otiles = (long long)a.groups * ((a.cout_g + 31) / 32) * ((a.n_total + 31) / 32);
     if (steps > 15 * 24 || otiles > kGvCounters) return false;                // at most 15 slices of at most 24 steps

@@ -746,7 +746,7 @@ int rb_streams_per_wg(int C, int batch, int t, int groups) {
 // 128 channels: every wave has an m-tile of its own, nothing to share.
 // Round 5: not for launches of <= 128 workgroups (few streams: at most one workgroup on half of the CUs) -- the ring's hand-over per group (a counted
 // wait + a barrier every one or two 16-k steps) costs a lone workgroup more than the second weight stream did: 1 / 32 streams 0.715 / 0.761 ms per
-// step with the ring, 0.707 / 0.752 without (tools/r5_s12.sh).
+// step with the ring, 0.707 / 0.752 without (experiments/sessions/r5_s12.sh).
 int rb_ring_slots(int C, int ntw, int spw, long long blocks) {
     static const int on = rb_knob("ADK_RB16_RING", 1);
     if (!on || (blocks <= 128 && on < 3)) return 0;
@@ -883,7 +883,7 @@ int launch_conv_rb16(const ConvArgs* c, int n, const int* keep, hipStream_t s) {
     // ADK_RB16_WARM: 0 never, 1 always, 2 = the round-3 rule (32 / 64 channels, any launch size).
     static const int warm_env = rb_knob("ADK_RB16_WARM", -1);
     // Round 5: not for launches of <= 128 workgroups either (few streams) -- there the touches cost more than they save: 1 / 8 / 32 streams
-    // 0.719 / 0.750 / 0.772 ms per step with them, 0.713 / 0.746 / 0.761 without (tools/r5_s11.sh); with them on the 128-channel chains too: 0.760 / 0.824 / 0.818.
+    // 0.719 / 0.750 / 0.772 ms per step with them, 0.713 / 0.746 / 0.761 without (experiments/sessions/r5_s11.sh); with them on the 128-channel chains too: 0.760 / 0.824 / 0.818.
     r.warm = warm_env == 2 ? (pl.C <= 64) : (warm_env >= 0 ? warm_env : (pl.C <= 64 && pl.blocks <= 384 && pl.blocks > 128));
 #if ADK_RB16_DBG & 1
     r.dbg_slot = g_rb_launch++;

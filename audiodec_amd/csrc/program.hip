@@ -268,7 +268,8 @@ struct adk_program {
     int* flags = nullptr;           // this program's sticky device flag word (bits as adk_debug_flags): what its launches report to; a slot of the device's pool
     bool profiling = false;
     bool fresh = true;              // no step since create / reset (ADK_OP_HIST_REPLICATE runs only then)
-    bool fresh_before = true;       // ... as it was before the last step (adk_program_rewind puts it back)
+    long long steps_since_reset = 0;   // steps taken since create / reset / set_fresh(1), rewinds subtracted: adk_program_rewind, applied any
+                                       // number of times in a row (ring extra_rows), restores `fresh` exactly when it is back at the first step
     bool replaying = false;         // the step in progress was asked for with ADK_STEP_REPLAY
     std::vector<hipEvent_t> ev;     // n_ops + 1 events when profiling
     std::vector<float> last_ms;
@@ -657,7 +658,6 @@ static int program_step(adk_program* p, int32_t frames, void* const* ext, int32_
     const int phase = (p->graph && !p->profiling && !p->fresh && frames == p->max_frames) ? graph_phase(p) : -1;
     const bool replay = phase >= 0 && p->seen[phase] && s != nullptr;      // the legacy default stream cannot be captured: eager there
     if (p->profiling) ADK_HIP_CHECK(hipEventRecord(p->ev[0], s));
-    p->fresh_before = p->fresh;
     for (int i = 0; i < n_ops; ++i) {
         if (replay && i == p->g_lo) {
             if (!p->gexec[phase]) {
@@ -701,6 +701,7 @@ static int program_step(adk_program* p, int32_t frames, void* const* ext, int32_
         if (p->rings[i].external < 0)
             p->cursor[i] = (int32_t)(((long long)p->cursor[i] + (long long)frames * p->rings[i].rate) % p->rows[i]);
     p->fresh = false;
+    ++p->steps_since_reset;
     return ADK_OK;
 }
 
@@ -750,6 +751,7 @@ extern "C" int adk_program_reset(adk_program* p, void* stream) {
         p->cursor[i] = 0;
     }
     p->fresh = true;
+    p->steps_since_reset = 0;
     return ADK_OK;
 }
 
@@ -767,13 +769,13 @@ extern "C" int adk_program_flags_post(adk_program* p, void* stream, int64_t* tic
     DeviceGuard guard(p->device);
     if (!p->post_host) {
         int* h = nullptr; int* hd = nullptr;
-        ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), ADK_POST_SLOTS * sizeof(int), hipHostMallocMapped));
+        ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), ADK_POST_SLOTS * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // coherent: host visibility of a posted word must not depend on HIP_HOST_COHERENT
         memset(h, 0, ADK_POST_SLOTS * sizeof(int));
         ADK_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0));
         p->post_host = h; p->post_host_dev = hd;
     }
     const int slot = (int)(p->post_next % ADK_POST_SLOTS);
-    if (!p->post_ev[slot]) ADK_HIP_CHECK(hipEventCreateWithFlags(&p->post_ev[slot], hipEventDisableTiming));
+    if (!p->post_ev[slot]) ADK_HIP_CHECK(hipEventCreateWithFlags(&p->post_ev[slot], hipEventDisableTiming | hipEventReleaseToSystem));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rc = flag_word_post(p->flags, p->post_host_dev + slot, s);
     if (rc != ADK_OK) return rc;
@@ -809,7 +811,10 @@ extern "C" int adk_program_rewind(adk_program* p, int32_t frames) {
             const long long back = ((long long)frames * p->rings[i].rate) % p->rows[i];
             p->cursor[i] = (int32_t)(((long long)p->cursor[i] - back + p->rows[i]) % p->rows[i]);
         }
-    p->fresh = p->fresh_before;               // the repeated step is the first one after a reset iff the rewound one was
+    // the repeated step is the first one after a reset iff the rewound one was -- also after several rewinds in a row (ABI 13: up to
+    // extra_rows / step of them): a counter, not one saved level
+    if (p->steps_since_reset > 0) --p->steps_since_reset;
+    p->fresh = p->steps_since_reset == 0;
     return ADK_OK;
 }
 
@@ -817,7 +822,8 @@ extern "C" int adk_program_get_fresh(const adk_program* p) { return p ? (p->fres
 
 extern "C" int adk_program_set_fresh(adk_program* p, int32_t fresh) {
     if (!p) return fail(ADK_ERR_ARG, "program_set_fresh: null program");
-    p->fresh = p->fresh_before = fresh != 0;
+    p->fresh = fresh != 0;
+    p->steps_since_reset = p->fresh ? 0 : (p->steps_since_reset > 0 ? p->steps_since_reset : (1ll << 40));   // "not fresh": no number of rewinds makes it fresh
     return ADK_OK;
 }
 

@@ -704,7 +704,7 @@ static int pool_ready(FlagPool& fp) {     // (g_pool_mu held, the pool's device 
     int* d = nullptr; int* h = nullptr; int* hd = nullptr;
     ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), kFlagSlots * sizeof(int)));
     ADK_HIP_CHECK(hipMemset(d, 0, kFlagSlots * sizeof(int)));
-    ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), kFlagSlots * sizeof(int), hipHostMallocMapped));
+    ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), kFlagSlots * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     memset(h, 0, kFlagSlots * sizeof(int));
     ADK_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0));
     fp.dev = d; fp.host = h; fp.host_dev = hd;

@@ -200,7 +200,12 @@ class StreamingPipeline:
         self.n_steps = 0
 
     def step(self, x):
-        """x (B, C, frames*hop) on the device -> y (B, out, frames*hop); returns as soon as the work is enqueued."""
+        """x (B, C, frames*hop) on the device -> y (B, out, frames*hop); returns as soon as the work is enqueued.
+
+        x may come straight from the caller's current stream (the transmitter stream waits for it).  y is written by the LAST pipeline
+        stream: consume it on the current stream only after exit() (which makes the current stream wait for the pipeline streams and
+        settles the guard), or make your stream wait yourself and -- with the deferred guard -- treat y as final only after settle() /
+        `depth` further steps."""
         t0 = time.perf_counter()
         self.n_steps += 1
         if self.log is None:
@@ -229,6 +234,12 @@ class StreamingPipeline:
         return y
 
     def _issue(self, x, b):
+        # x may have been produced on the caller's current stream right before this call (an H2D copy, any torch op): the transmitter
+        # stream reads it, so it waits for that stream -- free when the stream is idle -- and the caching allocator is told that s_tx
+        # uses x (with the guard off nothing else keeps x alive until the encoder's ring write has read it)
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            self.s_tx.wait_stream(torch.cuda.current_stream(self.dev))
+            x.record_stream(self.s_tx)
         with torch.cuda.stream(self.s_tx):
             z = self.tx.encode(x)
             if self.s_rvq is self.s_tx:

@@ -94,13 +94,74 @@ def rank_cpus(local_rank, local_world, cpus=None):
     return cpus[local_rank * per:(local_rank + 1) * per]
 
 
-def pin_rank(local_rank, local_world):
-    """Restrict this process to rank_cpus(...) (and tell the intra-op pools); returns the cpu list, or None where the platform has no
-    affinity call or the mask could not be set."""
+def numa_rank_cpus(local_rank, gpu_nodes, node_cpus, cpus):
+    """NUMA-aware variant of rank_cpus, pure (tests): gpu_nodes[r] = NUMA node of the GPU of local rank r (-1 / None: unknown),
+    node_cpus[n] = cpus of node n, cpus = the affinity mask.  Rank r gets an equal share of ITS GPU's node's cpus (those in the mask),
+    split among the local ranks whose GPUs sit on the same node, in rank order -- the launches of a rank then go out from cores next to
+    its GPU's PCIe root.  Returns None when any rank's node is unknown or a share would be empty: the caller falls back to rank_cpus()."""
+    if not gpu_nodes or any(n is None or n < 0 for n in gpu_nodes) or not 0 <= local_rank < len(gpu_nodes):
+        return None
+    allowed = set(cpus)
+    shares = {}
+    for node in set(gpu_nodes):
+        mine = [c for c in sorted(node_cpus.get(node, [])) if c in allowed]
+        ranks = [r for r, n in enumerate(gpu_nodes) if n == node]
+        per = len(mine) // len(ranks)
+        if per < 1:
+            return None
+        for k, r in enumerate(ranks):
+            shares[r] = mine[k * per:(k + 1) * per]
+    return shares[local_rank]
+
+
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(n_gpus):
+    """(NUMA node of each of the first n_gpus HIP devices, {node: cpus}) from sysfs -- the PCI address torch reports for a device ->
+    /sys/bus/pci/devices/<addr>/numa_node, /sys/devices/system/node/node<N>/cpulist; (None, {}) wherever any of that is missing."""
+    import os
+    try:
+        nodes = []
+        for i in range(n_gpus):
+            pr = torch.cuda.get_device_properties(i)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+                nodes.append(int(f.read().strip()))
+        node_cpus = {}
+        for n in set(nodes):
+            if n < 0:
+                return None, {}
+            with open(f"/sys/devices/system/node/node{n}/cpulist") as f:
+                node_cpus[n] = _parse_cpulist(f.read())
+        return nodes, node_cpus
+    except Exception:
+        return None, {}
+
+
+def pin_rank(local_rank, local_world, one_gpu=False):
+    """Restrict this process to its share of the host's cpus (and tell the intra-op pools); returns the cpu list, or None where the
+    platform has no affinity call or the mask could not be set.  The share: the cpus of the NUMA node of the rank's GPU
+    (/sys/bus/pci/devices/<gpu>/numa_node), divided among the ranks whose GPUs share that node (numa_rank_cpus) -- when the topology
+    cannot be read, or all ranks share one GPU (one_gpu: the rehearsal on a 1-GPU box), equal contiguous blocks of the affinity mask
+    (rank_cpus)."""
     import os
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
-    cpus = rank_cpus(local_rank, local_world)
+    cpus = None
+    if not one_gpu and torch.cuda.is_available() and torch.cuda.device_count() >= local_world:
+        nodes, node_cpus = gpu_numa_nodes(local_world)
+        if nodes is not None:
+            cpus = numa_rank_cpus(local_rank, nodes, node_cpus, sorted(os.sched_getaffinity(0)))
+    if not cpus:
+        cpus = rank_cpus(local_rank, local_world)
     try:
         os.sched_setaffinity(0, cpus)
     except OSError:

@@ -823,6 +823,43 @@ def extra_configs(root, dev, steps=100, warmup=10, check=True):
     return res
 
 
+def finish_line(out):
+    """Order of the JSON line.  The driver's record keeps the standard keys and the END of stdout, so the figures a reader needs besides
+    `value` are repeated, compact, as the LAST key (`summary`): the latency half of the metric, the guard legs, the roofline fractions of
+    the dominant kernel and of the north-star's named kernel.  `latency_ms` itself moves to the end too."""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    lat = out.pop("latency_ms", None)
+    cpu = out.pop("cpu_baseline", None)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu                  # (verbose: in front of the tail)
+    if lat is not None:
+        out["latency_ms"] = lat
+    ct, t5, roof = out.get("roofline_convtr") or {}, out.get("roofline_convtr_T5") or {}, out.get("roofline") or {}
+    out["summary"] = {
+        "value_frames_per_s": out.get("value"), "ms_per_step": out.get("ms_per_step"), "n_gpus": out.get("n_gpus"),
+        "unguarded": g(out, "unguarded", "value"), "guard_direct_calls": g(out, "guard_direct_calls", "value"),
+        "guard_every_step_synchronised": g(out, "guard_synchronous", "value"), "exact_f32": g(out, "other_precision", "value"),
+        "latency_ms": {"single_stream": g(lat, "encode_decode_single_stream_median"), "single_stream_guarded_direct_calls": g(out, "guard_direct_calls", "single_stream_ms"),
+                       "single_stream_guard_synchronised": g(out, "guard_synchronous", "single_stream_ms"),
+                       "batch": g(lat, "encode_decode_at_batch_median"), "batch_guarded_direct_calls": g(lat, "encode_decode_at_batch_median_guarded"),
+                       "cfg2_encoder_rvq_32_streams": g(out, "extra_configs", "cfg2_vctk_encoder_rvq_B32", "ms_per_step"),
+                       "cfg3_sym_codec_64_streams": g(out, "extra_configs", "cfg3_vctk_sym_full_B64", "ms_per_step"),
+                       "cfg4_v1_vocoder_256_streams": g(out, "extra_configs", "cfg4_v1_vocoder_B256", "ms_per_step")},
+        "roofline": {"kernel": roof.get("kernel"), "frac": roof.get("frac"), "frac_serial": roof.get("frac_serial"), "frac_source": roof.get("frac_source"),
+                     "traffic_bytes_per_launch": roof.get("traffic"), "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch")},
+        "north_star_kernel": {"kernel": ct.get("kernel"), "frac_of_8TBs": ct.get("frac"), "frac_serial": ct.get("frac_serial"), "avg_launch_us_serial": ct.get("avg_launch_us_serial"), "frac_events_serial": ct.get("frac_events_serial"),
+                              "T5_frac_serial": t5.get("frac_serial"), "T5_frac": t5.get("frac")},
+        "launches_per_step": roof.get("launches_per_step_all_kernels"),
+        "self_check_ok": g(out, "self_check", "ok"), "device_error_flags": out.get("device_error_flags"),
+    }
+    return out
+
+
 def self_launch(n):
     """Re-exec this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (rendezvous on
     127.0.0.1, a free port) and return its exit code.  Fewer than n visible HIP devices is an error (rc 2) unless the
@@ -911,7 +948,7 @@ def main():
     # one rank per GPU, each on its own block of host cpus (ADK_BENCH_PIN=0: leave the affinity alone)
     from audiodec_amd import shard as _shard
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    pinned = _shard.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), local_world) if os.environ.get("ADK_BENCH_PIN", "1") != "0" else None
+    pinned = _shard.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), local_world, one_gpu=os.environ.get("ADK_BENCH_ONE_GPU") == "1") if os.environ.get("ADK_BENCH_PIN", "1") != "0" else None
     coll_dev = dev if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
@@ -1048,7 +1085,7 @@ def main():
             "note": "issue = Python + runtime time to enqueue one batch (all programs, all HIP streams); must stay well below ms_per_step for the host not to be "
                     "the bottleneck -- with N ranks on one host each rank is pinned to 1/N of the cpus (audiodec_amd/shard.py: pin_rank)"},
         "distributed": {"world_size": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
-                        "ranks_per_gpu": 1, "steady_state_collectives": 0,
+                        "ranks_per_gpu": (world if os.environ.get("ADK_BENCH_ONE_GPU") == "1" else 1), "steady_state_collectives": 0,
                         "note": "one process per GPU, streams [r*B, (r+1)*B) on rank r, full weight replica per rank; the collectives of a run are the "
                                 "checkpoint broadcast, the barrier around the timed region and the max / gather of the elapsed times"},
         "realtime_streams_supported_per_gpu": int(frames / elapsed / world / 160.0),
@@ -1253,7 +1290,7 @@ def main():
         if isinstance(v_, dict) and "self_check" in v_:
             assert v_["self_check"]["ok"], f"parity check of {k_} failed: {v_['self_check']}"
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(finish_line(out)))
     if world > 1:
         dist.destroy_process_group()
 

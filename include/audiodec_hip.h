@@ -309,8 +309,9 @@ int adk_program_flags_post(adk_program* p, void* stream, int64_t* ticket);
 int adk_program_flags_poll(adk_program* p, int64_t ticket, int32_t block, int32_t* done, int32_t* flags);
 /* "Fresh" = no step since create / reset: the one state bit of a program besides its arena and cursors (the offline lowering's
  * ADK_OP_HIST_REPLICATE -- the replication pad of CausalConvTranspose1d.forward, layers/conv_layer.py:189-192 -- runs on a fresh
- * step only).  adk_program_rewind restores the value from before the rewound step; get / set carry it over to a program that
- * takes this one's place (the exact-f32 twin of the guard, also for offline programs). */
+ * step only).  adk_program_rewind restores the value from before the rewound step -- also when it is applied several times in a row
+ * (the program counts its steps since the last reset, rewinds subtracted); get / set carry the bit over to a program that takes this
+ * one's place (the exact-f32 twin of the guard, also for offline programs): set(0) marks "not fresh" for good, set(1) restarts the count. */
 int adk_program_get_fresh(const adk_program* p);
 int adk_program_set_fresh(adk_program* p, int32_t fresh);
 /* How many persistent workgroups the stream-K conv launches of this program use (multiple of 8; 0 = default = the whole

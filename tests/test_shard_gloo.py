@@ -77,3 +77,21 @@ def test_rank_cpus_are_disjoint_equal_blocks():
     assert shard.rank_cpus(1, 3, list(range(10))) == [3, 4, 5]  # 10 // 3 = 3 each, one cpu left unused
     assert shard.rank_cpus(0, 8, [0, 1]) == [0, 1]              # fewer cpus than ranks: no pinning
     assert shard.pin_rank(0, 1) is None                         # a single rank is left alone
+
+
+def test_numa_rank_cpus_follow_the_gpus_nodes():
+    """shard.numa_rank_cpus: a rank's cpus come from the NUMA node of ITS GPU, shared equally by the ranks on that node; unknown topology -> None
+    (pin_rank then falls back to equal blocks)."""
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    mask = list(range(256))
+    blocks = [shard.numa_rank_cpus(r, nodes, node_cpus, mask) for r in range(8)]
+    assert all(len(b) == 32 for b in blocks)
+    assert len(set().union(*blocks)) == 256
+    assert all(set(blocks[r]) <= set(node_cpus[nodes[r]]) for r in range(8))
+    assert blocks[0] == list(range(0, 32)) and blocks[4] == list(range(64, 96))
+    assert shard.numa_rank_cpus(1, [0, 1], node_cpus, list(range(0, 100))) == list(range(64, 100))     # only the cpus the mask allows
+    assert shard.numa_rank_cpus(0, [0, -1], node_cpus, mask) is None
+    assert shard.numa_rank_cpus(0, None, node_cpus, mask) is None
+    assert shard.numa_rank_cpus(0, [0, 0], {0: [5]}, mask) is None                                      # a share would be empty
+    assert shard._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
