@@ -6,13 +6,16 @@
 // (25.6 KB per stream and frame, written and read back by the two-launch form) never exists in memory.
 //
 // Per stream and frame: reads 100 rows x 768 B, writes 300 rows x 128 B -- 115 KB for 2 x 2.46 MFLOP; 29.5 MB per 256-stream launch.
-// One workgroup = one stream, wave w = time tile w (32 steps), built like conv_up16 around ONE round trip to memory:
-//   * every lane loads the B fragments of ITS time step for the 1x1 conv straight from the ring (24 x 16 B in flight per lane);
-//     both weight sets (2 x 48 KB of split-f16 fragments) go global -> LDS by LDS-DMA in the same round trip;
-//   * GEMM 1 (64 x 192 per step) leaves c in the accumulators; LeakyReLU(c), split into f16 hi / lo, is written to a 35 KB LDS
-//     buffer whose row 0 is the history row of the transposed conv (the last c of the previous call, from the state ring);
-//   * GEMM 2 (polyphase transposed conv: 96 rows x 2 taps x 64 channels) reads its B fragments from that buffer, tap 0 one row up;
-//   * outputs leave as 16-byte stores; of c only the LAST row goes to its ring (the next call's history).
+// One workgroup = one stream, wave w = time tile w (32 steps); every byte arrives by LDS-DMA (round 6; the register-fed form of round 3 is
+// experiments/conv_ou16_round3_register_fed.hip):
+//   * both weight sets (2 x 48 KB of split-f16 fragments) and the wave's 32 rows x 768 B of activations -- as six column blocks through a
+//     wave-private ring of three 4-KiB slots, XOR-swizzled through the DMA's source addresses -- see the kernel's own comment below;
+//   * GEMM 1 (64 x 192 per step) leaves c in the accumulators; LeakyReLU(c), split into f16 hi / lo, overwrites the wave's ring (row r of the
+//     tile at r * 272 B); the row in front of a wave's first step comes from the previous wave (halo rows; wave 0: the history row of the
+//     transposed conv, the last c of the previous call, from the state ring);
+//   * GEMM 2 (polyphase transposed conv: 96 rows x 2 taps x 64 channels) reads its B fragments from there, tap 0 one row up; every m-tile
+//     has its own accumulators and the finish is branch-free, so the stores of m-tile i issue beneath the MFMAs of m-tile i + 1;
+//   * outputs leave as 16-byte buffer stores; of c only the LAST row goes to its ring (the next call's history), behind everything else.
 // The operations per output element and their order are those of the two separate kernels (conv_sk16 for the 1x1 conv with
 // K = 192 = three unsplit chunks, conv_up16 for the transposed conv): the result is bit-identical.
 #include "adk_common.h"
@@ -26,8 +29,8 @@
 namespace adk {
 
 #if ADK_OU16_DBG & 1
-// [workgroup 0..1023][stamp]: 0 entry, 1 loads + LDS-DMA issued, 2 first barrier passed (everything landed), 3 GEMM 1 done (72 MFMAs),
-// 4 c written to LDS + second barrier passed, 5 GEMM 2 MFMAs and stores issued (exit)
+// [workgroup 0..1023][stamp]: 0 entry, 1 the 37 LDS-DMA instructions of the wave issued, 2 first barrier passed ({biases, W1, column block 0} landed),
+// 3 GEMM 1 done (72 MFMAs; column blocks 1-5 streamed in beneath it), 4 act(c) written to LDS + second barrier passed, 5 GEMM 2 MFMAs and stores issued (exit)
 __device__ unsigned long long g_ou_trace[1024 * 8];
 extern "C" int adk_debug_ou_trace(unsigned long long* out, int n) {
     if (n > 1024 * 8) n = 1024 * 8;
@@ -52,7 +55,8 @@ constexpr int OU_KS2 = 2 * OU_CM / 16;           // 2 taps x 64 channels = 8 chu
 constexpr int OU_RSC = 4 * OU_CM + 16;           // LDS row stride of the c buffer: [64 halfs hi][64 halfs lo][16 B pad]
 constexpr int OU_TMAX = 128;                     // steps of the 1x1 conv per workgroup (4 waves x 32)
 
-struct OuArgs { int ks1p; float inv_cout_real; int* err; };
+struct OuArgs { int ks1p; float inv_cout_real; int* err; unsigned out_bytes; };
+typedef unsigned u32x4o __attribute__((ext_vector_type(4)));
 
 template <int ACT>
 __device__ __forceinline__ float ou_act(float x, float slope) {
@@ -61,193 +65,10 @@ __device__ __forceinline__ float ou_act(float x, float slope) {
     return x;
 }
 
-// KS1 = 16-channel chunks of the 1x1 conv's input (192 channels: 12); MT2 = 32-row tiles of the transposed conv's GEMM (s * Cout / 32)
-template <int ACT, int KS1, int MT2>
-__global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs a2, OuArgs u) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.x;
-    const int T = a1.t_out;
-    const int t = wave * 32 + l31;
-    const bool valid = t < T;
-    const int tt = valid ? t : T - 1;                     // padded columns work on a copy of the last one; nothing of theirs is stored
-    OU_STAMP(0);
-
-    const int w1_bytes = 2 * u.ks1p * 2048, w2_bytes = MT2 * OU_KS2 * 2048;
-    unsigned char* w1l = lds;                              // [2 m-tiles][ks1p chunks][hi | lo][64 lanes][16 B]
-    unsigned char* w2l = lds + w1_bytes;                   // [MT2][8 chunks][hi | lo][64 lanes][16 B]
-    unsigned char* cbuf = w2l + w2_bytes;                  // [1 + OU_TMAX rows][OU_RSC]: row 0 = c[-1], row 1 + t = c[t]
-    float* b2l = reinterpret_cast<float*>(cbuf + (1 + OU_TMAX) * OU_RSC);   // [32 * MT2]
-    float* b1l = b2l + 32 * MT2;                           // [64]
-
-    // ---- loads of this lane, oldest first: biases, the history row of c, the B fragments of the 1x1 conv ----
-    float bias2_v = 0.f, bias1_v = 0.f;
-    if (a2.bias && tid < 32 * MT2) bias2_v = a2.bias[tid];
-    if (a1.bias && tid < OU_CM) bias1_v = a1.bias[tid];
-    float4 hrow = make_float4(0.f, 0.f, 0.f, 0.f);         // c[-1]: what the previous call left in front of the cursor of the 64-channel ring
-    if (tid < OU_CM / 4) hrow = *reinterpret_cast<const float4*>(a2.in + ((size_t)b * a2.in_rows + a2.in_row0) * a2.in_ch + a2.in_choff + 4 * tid);
-    float4 xr[KS1][2];
-    {
-        int row = a1.in_row0 + tt;
-        if (row >= a1.in_rows) row -= a1.in_rows;
-        const float4* p = reinterpret_cast<const float4*>(a1.in + ((size_t)b * a1.in_rows + row) * a1.in_ch + a1.in_choff + 8 * lh);
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) { xr[s][0] = p[4 * s]; xr[s][1] = p[4 * s + 1]; }
-    }
-    // ---- both weight sets: lane-linear copies global -> LDS (LDS-DMA, no registers), in the same round trip ----
-    {
-        const unsigned char* g1 = reinterpret_cast<const unsigned char*>(a1.wfrag) + (size_t)tid * 16;
-        const unsigned char* g2 = reinterpret_cast<const unsigned char*>(a2.wfrag) + (size_t)tid * 16;
-        unsigned char* l1 = w1l + wave * 1024;             // wave-uniform base; the lane offset is implicit
-        unsigned char* l2 = w2l + wave * 1024;
-        for (int i = 0; i < w1_bytes / 4096; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g1 + 4096 * i), (lptr_t)(l1 + 4096 * i), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT2 * OU_KS2 * 2048 / 4096; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g2 + 4096 * i), (lptr_t)(l2 + 4096 * i), 16, 0, 0);
-    }
-    OU_STAMP(1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (tid < 32 * MT2) b2l[tid] = bias2_v;
-    if (tid < OU_CM) b1l[tid] = bias1_v;
-    if (tid < OU_CM / 4) {                                 // history row: activation, split, into row 0 of the c buffer
-        const float x[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
-        f16x4u hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = ou_act<ACT>(x[e], a2.slope);
-            const _Float16 h = (_Float16)v;
-            hi[e] = h; lo[e] = (_Float16)((v - (float)h) * kOuLoScale);
-        }
-        *reinterpret_cast<f16x4u*>(cbuf + 8 * tid) = hi;
-        *reinterpret_cast<f16x4u*>(cbuf + 2 * OU_CM + 8 * tid) = lo;
-    }
-    // this wave's activation loads and its slices of W1 have landed (the other waves read them); the MT2 * 4 LDS-DMA pieces of W2,
-    // issued last, may still be in flight: they are only needed after GEMM 1 (timeline: profiles/r3_ou16_timeline.md)
-    if constexpr (MT2 == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (MT2 == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __syncthreads();
-    OU_STAMP(2);
-
-    bool bad = false;
-    // ---- GEMM 1: c[m][t] = sum_k W1[m][k] x[k][t], 64 rows (two m-tiles) x this wave's 32 steps ----
-    {
-        f32x16 am[2], ac[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { am[mt][e] = 0.f; ac[mt][e] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            const float x[8] = {xr[s][0].x, xr[s][0].y, xr[s][0].z, xr[s][0].w, xr[s][1].x, xr[s][1].y, xr[s][1].z, xr[s][1].w};
-            f16x8u bh, bl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const _Float16 h = (_Float16)x[e];
-                bh[e] = h; bl[e] = (_Float16)((x[e] - (float)h) * kOuLoScale);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const unsigned char* wp = w1l + (size_t)(mt * u.ks1p + s) * 2048 + lane * 16;
-                const f16x8u Ah = *reinterpret_cast<const f16x8u*>(wp);
-                const f16x8u Al = *reinterpret_cast<const f16x8u*>(wp + 1024);
-                am[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bh, am[mt], 0, 0, 0);
-                ac[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bl, ac[mt], 0, 0, 0);
-                ac[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh, ac[mt], 0, 0, 0);
-            }
-        }
-        OU_STAMP(3);
-        // c (+ bias): the last step's row goes to the 64-channel ring (the next call's history); act(c), split, to the LDS buffer
-        float* crow = nullptr;
-        if (valid && t == T - 1) {
-            int row = a1.out_cursor + t;
-            if (row >= a1.out_rows) row -= a1.out_rows;
-            crow = a1.out + ((size_t)b * a1.out_rows + row) * a1.out_ch + a1.out_choff;
-        }
-        unsigned char* lrow = cbuf + (1 + t) * OU_RSC;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int ml = mt * 32 + 8 * qd + 4 * lh;
-                float v[4] = {fmaf(ac[mt][4 * qd], kOuLoInv, am[mt][4 * qd]), fmaf(ac[mt][4 * qd + 1], kOuLoInv, am[mt][4 * qd + 1]),
-                              fmaf(ac[mt][4 * qd + 2], kOuLoInv, am[mt][4 * qd + 2]), fmaf(ac[mt][4 * qd + 3], kOuLoInv, am[mt][4 * qd + 3])};
-                if (valid) bad |= !(fabsf(v[0]) <= 3.0e38f) | !(fabsf(v[1]) <= 3.0e38f) | !(fabsf(v[2]) <= 3.0e38f) | !(fabsf(v[3]) <= 3.0e38f);
-                if (a1.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(b1l + ml);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (crow) *reinterpret_cast<float4*>(crow + ml) = make_float4(v[0], v[1], v[2], v[3]);
-                if (valid) {
-                    f16x4u hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y = ou_act<ACT>(v[e], a2.slope);
-                        const _Float16 h = (_Float16)y;
-                        hi[e] = h; lo[e] = (_Float16)((y - (float)h) * kOuLoScale);
-                    }
-                    *reinterpret_cast<f16x4u*>(lrow + 2 * ml) = hi;
-                    *reinterpret_cast<f16x4u*>(lrow + 2 * OU_CM + 2 * ml) = lo;
-                }
-            }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // W2 has landed
-    __syncthreads();
-    OU_STAMP(4);
-
-    // ---- GEMM 2: the polyphase transposed conv; k = (tap j, channel), tap 0 = the older row c[t-1] = buffer row t, tap 1 = row t + 1 ----
-    float* outb = a2.out + (size_t)b * a2.out_rows * a2.out_ch + a2.out_choff;
-    int orow0 = a2.out_cursor + t * a2.up;
-    orow0 %= a2.out_rows;
-    const unsigned char* xb = cbuf + tt * OU_RSC + 16 * lh;
-    f16x8u bh[OU_KS2], bl[OU_KS2];
-#pragma unroll
-    for (int s = 0; s < OU_KS2; ++s) {
-        const unsigned char* p = xb + (s / 4) * OU_RSC + 32 * (s % 4);
-        bh[s] = *reinterpret_cast<const f16x8u*>(p);
-        bl[s] = *reinterpret_cast<const f16x8u*>(p + 2 * OU_CM);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT2; ++mt) {
-        f32x16 am, ac;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { am[e] = 0.f; ac[e] = 0.f; }
-        const unsigned char* wp = w2l + (size_t)mt * OU_KS2 * 2048 + lane * 16;
-#pragma unroll
-        for (int s = 0; s < OU_KS2; ++s) {
-            const f16x8u Ah = *reinterpret_cast<const f16x8u*>(wp + s * 2048);
-            const f16x8u Al = *reinterpret_cast<const f16x8u*>(wp + s * 2048 + 1024);
-            am = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bh[s], am, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bl[s], ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh[s], ac, 0, 0, 0);
-        }
-        if (!valid) continue;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int ml = mt * 32 + 8 * qd + 4 * lh;       // GEMM row = phase * cout_real + co
-            float4 v = make_float4(fmaf(ac[4 * qd], kOuLoInv, am[4 * qd]), fmaf(ac[4 * qd + 1], kOuLoInv, am[4 * qd + 1]),
-                                   fmaf(ac[4 * qd + 2], kOuLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kOuLoInv, am[4 * qd + 3]));
-            bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
-            const float4 bb = *reinterpret_cast<const float4*>(b2l + ml);
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-            const int ph = (int)(((float)ml + 0.5f) * u.inv_cout_real);        // ml / cout_real, exact for these sizes
-            int r2 = orow0 + ph;
-            if (r2 >= a2.out_rows) r2 -= a2.out_rows;
-            *reinterpret_cast<float4*>(outb + (size_t)r2 * a2.out_ch + (ml - ph * a2.cout_real)) = v;
-        }
-    }
-    OU_STAMP(5);
-    if (bad) atomicOr(u.err, 8);
-}
-
-
 // ================================================================================================
-// Round 6: the same launch, fed by LDS-DMA (conv_ou16_dma_kernel; ADK_OU16_V=1 selects the register-fed kernel above for A/B).
+// Round 6: the launch fed by LDS-DMA (conv_ou16_dma_kernel).
 //
-// What the timeline of the kernel above said (profiles/r3_ou16_timeline.md, 256 streams): 4.4 us of its 12.5 us are the ISSUE of its 48
+// What the timeline of the register-fed kernel of round 3 said (profiles/r3_ou16_timeline.md, 256 streams): 4.4 us of its 12.5 us are the ISSUE of its 48
 // vector-memory instructions per wave -- every lane loads the B fragments of ITS time step, i.e. one wave instruction touches 32 ring rows
 // and uses 32 bytes of each: four times the cache lines a coalesced access needs, all of it before the first MFMA; another 1.9 us ("epilogue
 // 1") were the wait for ONE 256-byte store (the next call's history row of c) behind the s_waitcnt vmcnt(0) that W2's arrival needs.  Here:
@@ -260,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_kernel(ConvArgs a1, ConvArgs
 //   * no lane holds staged activations in registers (96 fewer), no ordinary vector load is left in the kernel -- biases and the history row
 //     of c arrive through one more DMA instruction -- so every s_waitcnt vmcnt is written here, counted, and none drains W2 early;
 //   * the history row of c for the next call goes to LDS in epilogue 1 and to memory behind GEMM 2's stores.
-// Per output element the operations and their order are those of the kernel above (and of conv_sk16 + conv_up16): bit-identical.
+// Per output element the operations and their order are those of the round-3 kernel, i.e. of conv_sk16 + conv_up16: bit-identical.
 #define OU_DMA16(gptr, m0val) do { unsigned m0_keep_; asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
                                                             : "=&s"(m0_keep_) : "v"(gptr), "s"(m0val) : "memory"); } while (0)      /* M0 is the compiler's: put back */
 constexpr int OU_SLOT = 4096;                    // one column block of a wave's tile: 32 rows x 128 B
@@ -344,7 +165,10 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_dma_kernel(ConvArgs a1, Conv
         for (int i = 0; i < W2B / 4096; ++i) OU_DMA16(g2 + 4096 * i, l2 + 4096u * i);
     }
     OU_STAMP(1);
-    // in flight per wave: 1 + 12 + 12 + 4 * MT2.  GEMM 1 may start when {stage, W1, block 0} have landed: blocks 1-2 and W2 stay in flight
+    // in flight per wave: 1 + 12 + 12 + 4 * MT2.  GEMM 1 may start when {stage, W1, block 0} have landed: blocks 1-2 and W2 stay in flight.
+    // (Issuing only {stage, W1, block 0} first and the rest beneath GEMM 1 was measured: first MFMA at 2.1 instead of 3.2 us, GEMM 1 4.1
+    // instead of 2.8 us -- the waves then stall at the DMA issue inside the loop; the CU's fill rate is the limit either way:
+    // profiles/r6_ou16_timeline.md)
     ou_wait_vm<8 + 4 * MT2>();
     __syncthreads();                                       // W1 is the four waves' copies
     OU_STAMP(2);
@@ -364,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_dma_kernel(ConvArgs a1, Conv
     const float* b2l = reinterpret_cast<const float*>(stage0 + 256);
     const float* b1l = reinterpret_cast<const float*>(stage0 + 640);
 
-    bool bad = false;
+    float chk = 0.f;                                        // stays 0 while every output is finite (columns past the end are copies of the last step)
     // ---- GEMM 1: c[m][t] = sum_k W1[m][k] x[k][t], 64 rows (two m-tiles) x this wave's 32 steps; k walks the column blocks ----
     {
         f32x16 am[2], ac[2];
@@ -436,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_dma_kernel(ConvArgs a1, Conv
                 const int ml = mt * 32 + 8 * qd + 4 * lh;
                 float v[4] = {fmaf(ac[mt][4 * qd], kOuLoInv, am[mt][4 * qd]), fmaf(ac[mt][4 * qd + 1], kOuLoInv, am[mt][4 * qd + 1]),
                               fmaf(ac[mt][4 * qd + 2], kOuLoInv, am[mt][4 * qd + 2]), fmaf(ac[mt][4 * qd + 3], kOuLoInv, am[mt][4 * qd + 3])};
-                if (valid) bad |= !(fabsf(v[0]) <= 3.0e38f) | !(fabsf(v[1]) <= 3.0e38f) | !(fabsf(v[2]) <= 3.0e38f) | !(fabsf(v[3]) <= 3.0e38f);
+                chk = fmaf(v[0], 0.f, chk); chk = fmaf(v[1], 0.f, chk); chk = fmaf(v[2], 0.f, chk); chk = fmaf(v[3], 0.f, chk);     // inf * 0 = NaN, NaN stays: chk == 0 <=> all finite
                 if (a1.bias) {
                     const float4 bb = *reinterpret_cast<const float4*>(b1l + ml);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -461,7 +285,6 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_dma_kernel(ConvArgs a1, Conv
     OU_STAMP(4);
 
     // ---- GEMM 2: the polyphase transposed conv; k = (tap j, channel), tap 0 = the older row c[t-1], tap 1 = c[t] ----
-    float* outb = a2.out + (size_t)b * a2.out_rows * a2.out_ch + a2.out_choff;
     int orow0 = a2.out_cursor + t * a2.up;
     orow0 %= a2.out_rows;
     const unsigned char* x0 = (l31 == 0 ? halo + wave * OU_RSC : ring + (l31 - 1) * OU_RSC) + 16 * lh;
@@ -473,43 +296,55 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_dma_kernel(ConvArgs a1, Conv
         bh[s] = *reinterpret_cast<const f16x8u*>(p);
         bl[s] = *reinterpret_cast<const f16x8u*>(p + 2 * OU_CM);
     }
-    // A fragments one step ahead over the whole (m-tile, 16-k step) sequence, two register sets: the next m-tile's first fragments are
-    // requested before this m-tile's stores
-    f16x8u Ah2[2], Al2[2];
-    auto load_a2 = [&](int i, int set) __attribute__((always_inline)) {
-        const unsigned char* wp = w2l + (size_t)i * 2048 + lane * 16;           // i = mt * 8 + s
-        Ah2[set] = *reinterpret_cast<const f16x8u*>(wp);
-        Al2[set] = *reinterpret_cast<const f16x8u*>(wp + 1024);
-    };
-    load_a2(0, 0);
+    // Every m-tile has its own accumulators and the body below is ONE basic block: the finish of m-tile mt (accumulator reads, bias, the
+    // finite check, address arithmetic, stores) is scheduled beneath the MFMAs of m-tile mt + 1 instead of holding them up -- with one pair of
+    // accumulators for all m-tiles the next MFMAs waited for the reads of the previous finish, and every `if` of the finish (bias, columns
+    // past the end) cut the block.  So: a missing bias is a select, columns past the end store out of bounds (raw buffer stores drop those).
+    // (Measured and dropped, profiles/r6_ou16_timeline.md: A fragments requested one step ahead in two register sets -- GEMM 2 3.9 instead of 3.1 us;
+    // finished rows through an LDS tile so that every store instruction writes 8 whole 128-byte rows -- all 12 stores then issue at the
+    // very end instead of beneath the next m-tile's MFMAs: 5.4 us.)
+    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(a2.out, 0, u.out_bytes, 0x00020000);
+    const unsigned out_base = ((unsigned)b * (unsigned)a2.out_rows * (unsigned)a2.out_ch + (unsigned)a2.out_choff) * 4u;
+    const unsigned row_bytes = (unsigned)a2.out_ch * 4u;
+    const bool has_b2 = a2.bias != nullptr;
+    const unsigned oob_mask = valid ? 0u : 0x80000000u;    // columns past the end: the store goes out of bounds (dropped), no branch
+    f32x16 am2[MT2], ac2[MT2];
 #pragma unroll
-    for (int mt = 0; mt < MT2; ++mt) {
-        f32x16 am, ac;
+    for (int mt = 0; mt < MT2; ++mt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { am[e] = 0.f; ac[e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { am2[mt][e] = 0.f; ac2[mt][e] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < OU_KS2; ++s) {
-            const int i = mt * OU_KS2 + s;
-            if (i + 1 < MT2 * OU_KS2) load_a2(i + 1, (i + 1) & 1);
-            am = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah2[i & 1], bh[s], am, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah2[i & 1], bl[s], ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al2[i & 1], bh[s], ac, 0, 0, 0);
-        }
-        if (!valid) continue;
+    for (int mt = 0; mt <= MT2; ++mt) {
+        if (mt < MT2) {
+            const unsigned char* wp = w2l + (size_t)mt * OU_KS2 * 2048 + lane * 16;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int ml = mt * 32 + 8 * qd + 4 * lh;       // GEMM row = phase * cout_real + co
-            float4 v = make_float4(fmaf(ac[4 * qd], kOuLoInv, am[4 * qd]), fmaf(ac[4 * qd + 1], kOuLoInv, am[4 * qd + 1]),
-                                   fmaf(ac[4 * qd + 2], kOuLoInv, am[4 * qd + 2]), fmaf(ac[4 * qd + 3], kOuLoInv, am[4 * qd + 3]));
-            bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
-            if (a2.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(b2l + ml);
-                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            for (int s = 0; s < OU_KS2; ++s) {
+                const f16x8u Ah = *reinterpret_cast<const f16x8u*>(wp + s * 2048);
+                const f16x8u Al = *reinterpret_cast<const f16x8u*>(wp + s * 2048 + 1024);
+                am2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bh[s], am2[mt], 0, 0, 0);
+                ac2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, bl[s], ac2[mt], 0, 0, 0);
+                ac2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, bh[s], ac2[mt], 0, 0, 0);
             }
-            const int ph = (int)(((float)ml + 0.5f) * u.inv_cout_real);        // ml / cout_real, exact for these sizes
-            int r2 = orow0 + ph;
-            if (r2 >= a2.out_rows) r2 -= a2.out_rows;
-            *reinterpret_cast<float4*>(outb + (size_t)r2 * a2.out_ch + (ml - ph * a2.cout_real)) = v;
+        }
+        if (mt > 0) {
+            const int m1 = mt - 1;                         // finish of the previous m-tile
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int ml = m1 * 32 + 8 * qd + 4 * lh;   // GEMM row = phase * cout_real + co
+                float4 v = make_float4(fmaf(ac2[m1][4 * qd], kOuLoInv, am2[m1][4 * qd]), fmaf(ac2[m1][4 * qd + 1], kOuLoInv, am2[m1][4 * qd + 1]),
+                                       fmaf(ac2[m1][4 * qd + 2], kOuLoInv, am2[m1][4 * qd + 2]), fmaf(ac2[m1][4 * qd + 3], kOuLoInv, am2[m1][4 * qd + 3]));
+                chk = fmaf(v.x, 0.f, chk); chk = fmaf(v.y, 0.f, chk); chk = fmaf(v.z, 0.f, chk); chk = fmaf(v.w, 0.f, chk);
+                float4 bb = *reinterpret_cast<const float4*>(b2l + ml);
+                bb.x = has_b2 ? bb.x : 0.f; bb.y = has_b2 ? bb.y : 0.f; bb.z = has_b2 ? bb.z : 0.f; bb.w = has_b2 ? bb.w : 0.f;
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                const int ph = (int)(((float)ml + 0.5f) * u.inv_cout_real);        // ml / cout_real, exact for these sizes
+                int r2 = orow0 + ph;
+                if (r2 >= a2.out_rows) r2 -= a2.out_rows;
+                const unsigned off = (out_base + (unsigned)r2 * row_bytes + (unsigned)(ml - ph * a2.cout_real) * 4u) | oob_mask;      // (offsets stay below 2^31: checked by the launcher)
+                u32x4o pv;
+                pv.x = __float_as_uint(v.x); pv.y = __float_as_uint(v.y); pv.z = __float_as_uint(v.z); pv.w = __float_as_uint(v.w);
+                __builtin_amdgcn_raw_buffer_store_b128(pv, rsrc_out, off, 0, 0);
+            }
         }
     }
     if (tid < OU_CM / 4) {                                  // the next call's history row of c, behind everything else
@@ -518,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void conv_ou16_dma_kernel(ConvArgs a1, Conv
         *reinterpret_cast<float4*>(a1.out + ((size_t)b * a1.out_rows + row) * a1.out_ch + a1.out_choff + 4 * tid) = *reinterpret_cast<const float4*>(clast + 4 * tid);
     }
     OU_STAMP(5);
-    if (bad) atomicOr(u.err, 8);
+    if (!(chk == 0.f)) atomicOr(u.err, 8);
 }
 
 bool ou_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -529,7 +364,8 @@ bool ou_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 bool conv_ou16_fusable(const ConvArgs& a1, const ConvArgs& a2) {
     if (!conv_up16_supported(a2) || a2.act_in == ADK_ACT_TANH) return false;
     if (!a1.wfrag || a1.taps != 1 || a1.stride != 1 || a1.up != 1 || a1.groups != 1 || a1.res || a1.act_in != ADK_ACT_NONE || a1.act_out != ADK_ACT_NONE) return false;
-    if (a1.cout_g != OU_CM || a1.cin_g != 192) return false;                           // instantiated: 192 -> 64
+    if (a1.cout_g != OU_CM || a1.cin_g != 32 * OU_NCB) return false;                   // instantiated: 192 -> 64 (six column blocks of 32 channels)
+    if ((unsigned long long)a2.batch * a2.out_rows * a2.out_ch * 4ull >= 0x7fffffffull) return false;      // buffer stores: 32-bit byte offsets
     if (a1.batch != a2.batch || a1.t_out != a2.t_out || a1.t_out < 1 || a1.t_out > OU_TMAX) return false;
     if (a2.in != a1.out || a2.in_rows != a1.out_rows || a2.in_ch != a1.out_ch || a2.in_choff != a1.out_choff) return false;
     if (a2.in_row0 != (a1.out_cursor + a1.out_rows - 1) % a1.out_rows) return false;    // one row of history, right in front of the new rows
@@ -541,23 +377,19 @@ bool conv_ou16_fusable(const ConvArgs& a1, const ConvArgs& a2) {
 int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s) {
     if (!conv_ou16_fusable(a1, a2)) return ADK_ERR_STATE;
     if (a1.n_total == 0) return ADK_OK;
-    static int variant = -1;                               // ADK_OU16_V: 2 (default) = the LDS-DMA-fed kernel of round 6, 1 = the register-fed kernel of round 3 (A/B)
-    if (variant < 0) { const char* e = getenv("ADK_OU16_V"); variant = (e && atoi(e) == 1) ? 1 : 2; }
     OuArgs u;
     u.ks1p = (a1.ktot + 63) / 64 * 4;
     u.inv_cout_real = 1.0f / (float)a2.cout_real;
     u.err = conv_err_word(a1);
+    u.out_bytes = (unsigned)((unsigned long long)a2.batch * a2.out_rows * a2.out_ch * 4ull);        // < 2^31: conv_ou16_fusable
     const int mt2 = a2.cout_g / 32;
-    const bool dma = variant == 2 && u.ks1p == 2 * OU_NCB;
-    const size_t lds = dma ? (size_t)2 * u.ks1p * 2048 + (size_t)mt2 * OU_KS2 * 2048 + (size_t)4 * OU_RING + (size_t)4 * OU_RSC + 16 + 4 * 1024 + OU_CM * sizeof(float)
-                           : (size_t)2 * u.ks1p * 2048 + (size_t)mt2 * OU_KS2 * 2048 + (size_t)(1 + OU_TMAX) * OU_RSC + (size_t)(32 * mt2 + OU_CM) * sizeof(float);
-    // a function attribute belongs to ONE instantiation (and one device): the flags are keyed by the (ACT, MT2, variant) triple -- every
+    const size_t lds = (size_t)2 * u.ks1p * 2048 + (size_t)mt2 * OU_KS2 * 2048 + (size_t)4 * OU_RING + (size_t)4 * OU_RSC + 16 + 4 * 1024 + OU_CM * sizeof(float);
+    // a function attribute belongs to ONE instantiation (and one device): the flags are keyed by the (ACT, MT2) pair -- every
     // instantiation decays to the same pointer type, so a flag inside a generic lambda over that pointer would be shared by all of them
-    auto go = [&](auto act, auto mt, auto var) -> int {
+    auto go = [&](auto act, auto mt) -> int {
         constexpr int ACT = decltype(act)::value, MT2 = decltype(mt)::value;
-        constexpr bool DMA = decltype(var)::value;
-        auto kern = [] { if constexpr (DMA) return conv_ou16_dma_kernel<ACT, MT2>; else return conv_ou16_kernel<ACT, 12, MT2>; }();
-        static bool attr_set_dev[kMaxDevices] = {};         // one array per (ACT, MT2, variant): the lambda's operator() is instantiated per tag type triple
+        auto kern = conv_ou16_dma_kernel<ACT, MT2>;
+        static bool attr_set_dev[kMaxDevices] = {};         // one array per (ACT, MT2): the lambda's operator() is instantiated per tag type pair
         bool& attr_set = attr_set_dev[current_device()];
         if (!attr_set) {
             ADK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -567,14 +399,10 @@ int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s) {
         ADK_HIP_CHECK(hipGetLastError());
         return ADK_OK;
     };
-    auto by_var = [&](auto act, auto mt) -> int {
-        if (dma) return go(act, mt, std::true_type());
-        return go(act, mt, std::false_type());
-    };
     auto by_mt = [&](auto act) -> int {
-        if (mt2 == 1) return by_var(act, std::integral_constant<int, 1>());
-        if (mt2 == 2) return by_var(act, std::integral_constant<int, 2>());
-        return by_var(act, std::integral_constant<int, 3>());
+        if (mt2 == 1) return go(act, std::integral_constant<int, 1>());
+        if (mt2 == 2) return go(act, std::integral_constant<int, 2>());
+        return go(act, std::integral_constant<int, 3>());
     };
     if (a2.act_in == ADK_ACT_ELU) return by_mt(std::integral_constant<int, ADK_ACT_ELU>());
     if (a2.act_in == ADK_ACT_LEAKY) return by_mt(std::integral_constant<int, ADK_ACT_LEAKY>());

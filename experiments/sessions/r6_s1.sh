@@ -9,7 +9,7 @@ for v in 1 2; do for b in 256 1; do
   echo "== trace ADK_OU16_V=$v streams=$b"; ADK_OU16_V=$v timeout 300 python tools/ou16_trace.py $b 2>&1 | grep -v "^Load\|amdgpu.ids" | tee -a gpurun_out/r6s1_trace_v$v.log
 done; done
 ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-extra-configs --no-other-precision --no-guarded --no-t5 --no-self-check"
-for r in 1 2; do for v in 1 2; do
+for r in 1; do for v in 1 2; do
   ADK_OU16_V=$v timeout 600 python bench.py $ARGS --dump-ops gpurun_out/r6s1_ops_v${v}_$r.csv > gpurun_out/r6s1_v${v}_$r.json 2> gpurun_out/r6s1_v${v}_$r.err
   echo "== ADK_OU16_V=$v round $r rc=$?"
   python - <<PY

@@ -12,7 +12,10 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "dbg", "ou1", "libaudiodec_hip.so")
+LIB = os.environ.get("ADK_OU16_TRACE_LIB") or os.path.join(ROOT, "tools", "dbg", "ou1", "libaudiodec_hip.so")
+
+
+EXTRA = []
 
 
 def build():
@@ -25,7 +28,7 @@ def build():
             objs.append(os.path.join(ROOT, "audiodec_amd", "csrc", ".obj", base + ".o"))
             continue
         o = os.path.join(out, base + ".o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DADK_OU16_DBG=1", "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DADK_OU16_DBG=1"] + EXTRA + [ "-I", os.path.join(ROOT, "include"), "-c", s, "-o", o])
         objs.append(o)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs)
     print(LIB)
@@ -64,8 +67,8 @@ def main():
     t0 = a[:, 0].min()
     print(f"{B} workgroups (one per stream), 4 waves each; times in us (10 ns ticks); launch span (first entry -> last exit) {(a[:, 5].max() - t0) / 100.0:.2f}")
     print(f"workgroup entry spread {(a[:, 0].max() - t0) / 100.0:.2f}; median workgroup duration {np.median(a[:, 5] - a[:, 0]) / 100.0:.2f}")
-    names = ["issue: 24 x 16 B activation loads per lane + 96 KB weight LDS-DMA", "wait: loads + DMA landed, first barrier",
-             "GEMM 1 (72 MFMAs per wave, conversion of the fragments)", "epilogue 1: c -> LDS (act, split), second barrier",
+    names = ["issue: 37 LDS-DMA instructions per wave (biases + c[-1], W1, column blocks 0-2 of the wave's tile, W2)", "wait: {biases, W1, block 0} landed, first barrier",
+             "GEMM 1 (72 MFMAs per wave; blocks 1-5 stream in beneath it; f16 split of the fragments)", "epilogue 1: act(c), split -> LDS, second barrier",
              "GEMM 2 (72 MFMAs per wave) + 12 x 16 B stores per lane issued"]
     for i, n in enumerate(names):
         d = (a[:, i + 1] - a[:, i]) / 100.0
