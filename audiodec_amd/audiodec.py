@@ -11,7 +11,7 @@ from typing import Union
 
 import torch
 
-from . import native
+from . import lazy_guard, native
 from .configs import assign_model  # noqa: F401  (utils/audiodec.py:109-179)
 from .stream import AudioCodec, AudioCodecStreamer
 from .stream_generator import AutoEncoderStreamGenerator as generator_audiodec
@@ -66,6 +66,28 @@ class AudioDec(AudioCodec):
         decoder.load_state_dict(torch.load(checkpoint, map_location="cpu")["model"]["generator"])
         return decoder.configure(self.num_streams, self.max_frames).set_guard(self.guard)
 
+    def load_transmitter(self, encoder_checkpoint):
+        super().load_transmitter(encoder_checkpoint)
+        self._share_logs()
+
+    def _share_logs(self):
+        """One lazy_guard.CallLog per device for the generators of this object: results that feed each other (encode -> quantize -> lookup ->
+        decode) are verified -- and, after an f16 range overflow, repeated -- in call order."""
+        by_dev = {}
+        for g in (self.tx_encoder, self.rx_encoder, self.decoder):
+            if g is None or g._device is None:
+                continue
+            key = str(g._device)
+            if key not in by_dev:
+                by_dev[key] = g._log if g._log is not None else lazy_guard.CallLog(g._dev())
+            g.share_log(by_dev[key])
+
+    def settle(self):
+        """Every direct call made through this object's generators is verified (and repaired if need be) when this returns."""
+        for g in (self.tx_encoder, self.rx_encoder, self.decoder):
+            if g is not None:
+                g.settle()
+
     def load_receiver(self, encoder_checkpoint, decoder_checkpoint):
         # bin/stream.py:65-77.  The receiver-side encoder only supplies the codebook and the warm-up
         # zq (its conv state is never stepped again), so it carries a single stream.
@@ -80,6 +102,7 @@ class AudioDec(AudioCodec):
         self.decoder.eval().to(self.rx_device)
         self.decoder.initial_decoder(zq)
         print("Load decoder: %s" % (decoder_checkpoint))
+        self._share_logs()
 
     def get_hop_length(self, checkpoint):
         # utils/audiodec.py:58-62

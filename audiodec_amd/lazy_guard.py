@@ -100,8 +100,10 @@ class _Call:
 class CallLog:
     """Unverified direct calls of the generators that share this log, oldest first (see the module docstring)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, drain=None):
+        """device: the HIP device of the generators that share the log; drain() (tests) replaces the device synchronisation of a repair."""
         self.device = device
+        self._drain = drain if drain is not None else (lambda: torch.cuda.synchronize(device) if device is not None else torch.cuda.synchronize())
         self.lock = threading.RLock()
         self.pending = collections.deque()
         self.in_redo = False
@@ -188,8 +190,7 @@ class CallLog:
 
     # ---- repair ----
     def _recover(self):
-        dev = self.device
-        torch.cuda.synchronize(dev) if dev is not None else torch.cuda.synchronize()
+        self._drain()                                        # everything issued has finished: every post can be read
         calls = list(self.pending)
         first, culprit, by_prog = None, None, {}
         for i, c in enumerate(calls):
@@ -226,7 +227,7 @@ class CallLog:
                         c.gen._replay = False
                     if new.data_ptr() != c.out.data_ptr():
                         c.out.copy_(new.reshape(c.out.shape))
-            torch.cuda.synchronize(dev) if dev is not None else torch.cuda.synchronize()
+            self._drain()
         finally:
             self.in_redo = False
         self.verified += len(redo)

@@ -32,7 +32,7 @@ import warnings
 
 import torch
 
-from . import native
+from . import lazy_guard, native
 
 _STREAM_POOL = {}
 
@@ -167,6 +167,9 @@ class StreamingPipeline:
 
     def enter(self):
         """All pipeline streams start after whatever ran on the current stream."""
+        for g in (self.tx, self.rx, self.dec):               # direct calls made so far (the warm-up) are verified before the pipeline takes over
+            if g is not None and hasattr(g, "settle"):
+                g.settle()
         cur = torch.cuda.current_stream(self.dev)
         for s in self._all():
             s.wait_stream(cur)
@@ -223,11 +226,11 @@ class StreamingPipeline:
         t1 = time.perf_counter()
         self.t_guard += t1 - t0
         b = _Batch(frames)
-        self.tx._defer = self.dec._defer = b.steps
+        self.tx._defer = self.rx._defer = self.dec._defer = b.steps      # (this object owns the guard of the batch: the generators' own call logs are bypassed)
         try:
             y = self._issue(x, b)
         finally:
-            self.tx._defer = self.dec._defer = None
+            self.tx._defer = self.rx._defer = self.dec._defer = None
         b.x, b.y = x, y
         self.log.push(b)
         self.t_issue += time.perf_counter() - t1
@@ -237,9 +240,11 @@ class StreamingPipeline:
         # x may have been produced on the caller's current stream right before this call (an H2D copy, any torch op): the transmitter
         # stream reads it, so it waits for that stream -- free when the stream is idle -- and the caching allocator is told that s_tx
         # uses x (with the guard off nothing else keeps x alive until the encoder's ring write has read it)
-        if isinstance(x, torch.Tensor) and x.is_cuda:
-            self.s_tx.wait_stream(torch.cuda.current_stream(self.dev))
-            x.record_stream(self.s_tx)
+        if isinstance(x, torch.Tensor):
+            xp = lazy_guard.plain(x)
+            if xp.is_cuda:
+                self.s_tx.wait_stream(torch.cuda.current_stream(self.dev))
+                xp.record_stream(self.s_tx)
         with torch.cuda.stream(self.s_tx):
             z = self.tx.encode(x)
             if self.s_rvq is self.s_tx:
@@ -249,7 +254,7 @@ class StreamingPipeline:
         if self.s_rvq is not self.s_tx:
             with torch.cuda.stream(self.s_rvq):
                 self.s_rvq.wait_event(ev)
-                z.record_stream(self.s_rvq)
+                lazy_guard.plain(z).record_stream(self.s_rvq)
                 idx = self.tx.quantize(z)
                 ev = torch.cuda.Event()
                 ev.record(self.s_rvq)
@@ -258,7 +263,7 @@ class StreamingPipeline:
             b.z, b.idx = z, idx
         with torch.cuda.stream(self.s_rx):
             self.s_rx.wait_event(ev)
-            idx.record_stream(self.s_rx)
+            lazy_guard.plain(idx).record_stream(self.s_rx)
             zq = self.rx.lookup(idx)
             if self.n_dec < 2:
                 return self.dec.decode(zq)
@@ -268,7 +273,7 @@ class StreamingPipeline:
         for i, st in enumerate(self.s_more, 1):
             with torch.cuda.stream(st):
                 st.wait_event(ev)
-                mid.record_stream(st)
+                lazy_guard.plain(mid).record_stream(st)
                 mid = self.dec.decode_stage(i, mid)
                 ev = torch.cuda.Event()
                 ev.record(st)
@@ -299,6 +304,21 @@ class StreamingPipeline:
             if not culprit.split16 or culprit.twin_builder is None or culprit.demoted:
                 raise native.NativeError("StreamingPipeline: a program without an exact-f32 twin reported an f16 range overflow")
             culprit.demote()
+        gens = [g for g in (self.tx, self.rx, self.dec) if g is not None]
+        modes = [getattr(g, "guard_mode", None) for g in gens]
+        for g in gens:
+            g.guard_mode = "sync"                                # the repeats are checked step by step, before the next one is issued
+        try:
+            self._repeat(batches)
+        finally:
+            for g, m_ in zip(gens, modes):
+                g.guard_mode = m_
+        torch.cuda.synchronize(self.dev)
+        self.enter()                                         # the pipeline streams continue behind the repeats
+        warnings.warn(f"StreamingPipeline: an operand left the f16 range (|v| > 65504) in a split-f16 conv; the last {len(batches)} batch(es) "
+                      "were repeated with the exact-f32 kernels for the program(s) concerned, which continue on them", RuntimeWarning, stacklevel=4)
+
+    def _repeat(self, batches):
         with torch.no_grad():
             for b in batches:
                 self.tx._replay = True                       # the caller's rows are still in the encoder's input ring
@@ -311,7 +331,3 @@ class StreamingPipeline:
                 b.z.copy_(z)
                 b.idx.copy_(idx)
                 b.y.copy_(y.reshape(b.y.shape))
-        torch.cuda.synchronize(self.dev)
-        self.enter()                                         # the pipeline streams continue behind the repeats
-        warnings.warn(f"StreamingPipeline: an operand left the f16 range (|v| > 65504) in a split-f16 conv; the last {len(batches)} batch(es) "
-                      "were repeated with the exact-f32 kernels for the program(s) concerned, which continue on them", RuntimeWarning, stacklevel=4)

@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import arch, native, program
+from . import arch, lazy_guard, native, program
 
 # keyword defaults of the reference constructors (AudioDec.py:169-189, HiFiGAN.py:225-241)
 _AE_DEFAULTS = dict(
@@ -64,7 +64,12 @@ class _StreamBase:
         # steps a program can be taken back by rewind() beyond the last one: extra ring rows (HipProgram(rewind_depth=...)).  What the
         # deferred guard of pipeline.StreamingPipeline needs (it finds a failed step one to `depth` steps late); 0 = none
         self.rewind_depth = int(os.environ.get("ADK_REWIND_DEPTH", "4"))
-        self._defer = None              # a list while a pipeline owns the guard: _step appends (program, frames, ticket) and does not wait
+        self._defer = None              # a list while a pipeline / the call log owns the guard: _step appends (program, frames, ticket) and does not wait
+        # how a direct call is guarded: "lazy" (default) -- the check of a call is posted behind it and read when its result is first looked at
+        # (lazy_guard.py: results come back as GuardedTensor; needs rewind_depth >= 1); "sync" -- one stream synchronisation per program step
+        # before the call returns (rounds 3-5; ADK_GUARD_MODE=sync)
+        self.guard_mode = os.environ.get("ADK_GUARD_MODE", "lazy")
+        self._log = None                # lazy_guard.CallLog, made on first use or shared by the facade (share_log)
         self._replay = False            # the next steps repeat rewound ones: programs skip their ring writes (HipProgram.step(replay=True))
         self._warm = {}
 
@@ -85,6 +90,7 @@ class _StreamBase:
         if num_streams < 1 or max_frames < 1:
             raise ValueError("num_streams and max_frames must be >= 1")
         if (num_streams, max_frames) != (self.num_streams, self.max_frames):
+            self.settle()
             self.num_streams, self.max_frames = int(num_streams), int(max_frames)
             self._drop_programs()
         return self
@@ -92,29 +98,67 @@ class _StreamBase:
     def set_rewind_depth(self, depth):
         """Extra ring rows for `depth` more rewindable steps (see __init__).  Rebuilds the programs: call it before the warm-up."""
         if int(depth) != self.rewind_depth:
+            self.settle()
             self.rewind_depth = max(0, int(depth))
             self._drop_programs()
         return self
 
-    def set_guard(self, on=True):
+    def set_guard(self, on=True, mode=None):
         """(on=None: keep the current setting -- the constructor's, i.e. ADK_GUARD, default on.)
-        guard=True (default): every program step is followed by a check of the program's device flag word (one stream
-        synchronisation per step).  A split-f16 step that met an operand beyond the f16 range is REPEATED on the exact-f32
+        guard=True (default): every program step is followed by a check of the program's device flag word.  mode "lazy" (default): the
+        check is posted behind the step and read when the call's result is first looked at, or by a later call (lazy_guard.py) -- direct
+        calls then cost what unguarded ones do; mode "sync": one stream synchronisation per step before the call returns.
+        A split-f16 step that met an operand beyond the f16 range is REPEATED on the exact-f32
         kernels -- ring cursors rewound, state carried over, same inputs: exact, because a step only reads history rows earlier
         steps wrote -- and the program stays on them from then on (a warning says so); any other device-side failure raises
         here, at the step that caused it.  guard=False: nothing synchronises; failures surface at the caller's next
         native.raise_on_device_flags() (asynchronous multi-stream pipelines: bench.py).  Streaming and offline programs
         (set_offline) are repaired alike: the rewind also restores the "first step after reset" bit the offline lowering's
         replication pad depends on."""
+        self.settle()
         if on is not None:
             self.guard = bool(on)
+        if mode is not None:
+            if mode not in ("lazy", "sync"):
+                raise ValueError("guard mode must be 'lazy' or 'sync'")
+            self.guard_mode = mode
         return self
+
+    # ---- the lazy guard of direct calls (lazy_guard.py) ----
+    def share_log(self, log):
+        """Use `log` (a lazy_guard.CallLog) for this generator's direct calls: generators whose results feed each other on one device share
+        one, so that a repair can repeat the calls that consumed a bad result (AudioDec does this for its three generators)."""
+        if log is not self._log:
+            self.settle()
+            self._log = log
+        return self
+
+    def settle(self):
+        """Every direct call made so far is verified (and repaired if need be) when this returns."""
+        if self._log is not None:
+            self._log.settle()
+
+    def _call_log(self):
+        """The log a direct call is recorded in, or None: guard off / mode "sync" / a pipeline owns the guard (_defer) / the rings carry no
+        rows to rewind by / offline programs / the call is a repeat made by the log itself."""
+        if not self.guard or self.guard_mode != "lazy" or self._defer is not None or self.rewind_depth < 1 or self.offline:
+            return None
+        if self._log is None:
+            self._log = lazy_guard.CallLog(self._dev())
+        return None if self._log.in_redo else self._log
+
+    def _guarded(self, impl, args, progs, frames):
+        log = self._call_log()
+        if log is None:
+            return impl(*[lazy_guard.plain(a) for a in args])
+        return log.run(self, impl, args, progs() if callable(progs) else progs, frames)
 
     def set_split16(self, on=True):
         """Split-precision kernels for the layers that have one (default on; ADK_SPLIT16=0 flips it): f32 operands carried
         as f16 hi + f16 lo/2048, three f16 MFMAs per product sum, f32 accumulation (csrc/conv_rl16.hip).  Off =
         exact-f32 matrix-core arithmetic everywhere."""
         if bool(on) != self.split16:
+            self.settle()
             self.split16 = bool(on)
             self._drop_programs()
         return self
@@ -125,6 +169,7 @@ class _StreamBase:
         their cursors cycle with a short period (more history rows than the layers need; state memory grows ~1.5x).  Results are
         bit-identical to the eager path.  Default off (env ADK_GRAPH=1 flips it)."""
         if bool(on) != self.graph:
+            self.settle()
             self.graph = bool(on)
             self._drop_programs()
         return self
@@ -178,6 +223,7 @@ class _StreamBase:
         instead of a zero pad_buffer.  Everything else (zero left-pad of CausalConv1d.forward) already
         equals streaming from the reset state."""
         if bool(offline) != self.offline:
+            self.settle()
             self.offline = bool(offline)
             self._drop_programs()
         return self
@@ -194,6 +240,7 @@ class _StreamBase:
         running.  (The reference has one stream per object and can only reset everything.)"""
         if not 0 <= b < self.num_streams:
             raise IndexError(f"stream {b} out of range 0..{self.num_streams - 1}")
+        self.settle()                                          # (a repair of an unverified call would rewind across the reset)
         for name, prog in self._programs().items():
             if prog is None:
                 continue
@@ -206,6 +253,7 @@ class _StreamBase:
             prog.restore_stream_state(b, self._warm[name] if warm else None)
 
     def _capture_warm(self, name, prog):
+        self.settle()
         self._warm[name] = prog.capture_stream_state(0)
 
     def load_state_dict(self, state_dict, strict=True):
@@ -221,6 +269,7 @@ class _StreamBase:
             if k in state_dict and tuple(state_dict[k].shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {k}: copying a param with shape {tuple(state_dict[k].shape)} "
                                    f"from checkpoint, the shape in current model is {tuple(shape)}.")
+        self.settle()
         self._sd = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         for k, v in self._sd.items():
             if k.endswith(".pad_buffer") and bool((v != 0).any()):
@@ -356,6 +405,10 @@ class AutoEncoderStreamGenerator(_StreamBase):
 
     def encode(self, x):
         """(B, C, L) -> z (B', code_dim, ceil(L/hop))   (AudioDec.py:228-234)."""
+        frames = -(-int(lazy_guard.plain(x).shape[-1]) // self.hop)
+        return self._guarded(self._encode, (x,), lambda: [self._encoder()], frames)
+
+    def _encode(self, x):
         dev = self._dev()
         (batch, channel, length) = x.size()
         if channel != self.input_channels:
@@ -380,6 +433,9 @@ class AutoEncoderStreamGenerator(_StreamBase):
 
     def quantize(self, z):
         """z (B, code_dim, T) -> idx (n_q, T) for B == 1, (n_q, B, T) otherwise  (AudioDec.py:237-239)."""
+        return self._guarded(self._quantize, (z,), [], 0)
+
+    def _quantize(self, z):
         dev = self._dev()
         embed, enorm = self._quantizer()
         B, D, T = z.shape
@@ -395,6 +451,9 @@ class AutoEncoderStreamGenerator(_StreamBase):
     def quantizer_forward(self, z):
         """Quantizer.forward in eval mode (quantizer.py:32-35 -> ResidualVQ.forward, vq_module.py:119-134):
         z (B, code_dim, T) -> zq (B, code_dim, T), the sum of the straight-through stage outputs."""
+        return self._guarded(self._quantizer_forward, (z,), [], 0)
+
+    def _quantizer_forward(self, z):
         dev = self._dev()
         embed, enorm = self._quantizer()
         B, D, T = z.shape
@@ -409,6 +468,9 @@ class AutoEncoderStreamGenerator(_StreamBase):
 
     def lookup(self, idx):
         """idx (n_q, T) -> zq (1, T, code_dim); (n_q, B, T) -> (B, T, code_dim)  (AudioDec.py:242-243)."""
+        return self._guarded(self._lookup, (idx,), [], 0)
+
+    def _lookup(self, idx):
         dev = self._dev()
         if self._codebook is None:
             self.initial()
@@ -427,7 +489,7 @@ class AutoEncoderStreamGenerator(_StreamBase):
     def pack(self, idx, check=True):
         """Emitted indices -> uint8 payload (B, T, n_q*bits/8): 10 bytes per frame for 8 x 1024 codes."""
         from . import wire
-        return wire.pack_codes(idx.to(self._dev()), self.size, check)
+        return wire.pack_codes(idx.to(self._dev()), self.size, check)        # (a guarded idx settles its log here: the payload is about to leave)
 
     def unpack(self, payload):
         from . import wire
@@ -442,13 +504,23 @@ class AutoEncoderStreamGenerator(_StreamBase):
 
     def decode(self, zq):
         """zq (B, T, code_dim) -> y (B, out_channels, T*hop)  (AudioDec.py:246-247)."""
+        return self._guarded(self._decode, (zq,), lambda: [self._decoder()], _frames_of(zq, 1))
+
+    def _decode(self, zq):
         return _decode_common(self, self._decoder(), zq, self.dim, self.hop, self.output_channels)
 
     def reset_buffer(self):
         """Zero every state ring (AudioDec.py:250-256)."""
+        self.settle()
         for pr in (self._enc, self._dec):
             if pr is not None:
                 pr.reset()
+
+
+def _frames_of(t, rows_per_frame):
+    """Hops a decode call of (B, T * rows_per_frame, C) steps its programs by (0 for anything that is not such a tensor: the call raises)."""
+    t = lazy_guard.plain(t)
+    return int(t.shape[1]) // max(1, rows_per_frame) if isinstance(t, torch.Tensor) and t.dim() == 3 else 0
 
 
 def _decode_common(self, prog, zq, dim, hop, out_ch=1):
@@ -539,6 +611,10 @@ class HiFiGANStreamGenerator(_StreamBase):
     def decode_stage(self, i, x):
         """Program i of a multi-stage lowering: 0 takes c (B, T, in_channels); the last returns (B, 1, T*hop); the
         hand-over tensors in between are (B, T*rate, channels) channel-last."""
+        r_in = 1 if i == 0 else program.hifigan_stage_boundary(self.params, self.cuts[i - 1])[1]
+        return self._guarded(lambda x_: self._decode_stage(i, x_), (x,), lambda: [self._decoder_stages()[i]], _frames_of(x, r_in))
+
+    def _decode_stage(self, i, x):
         progs = self._decoder_stages()
         x = x.to(device=self._dev(), dtype=torch.float32)
         if i == 0:
@@ -563,12 +639,13 @@ class HiFiGANStreamGenerator(_StreamBase):
         """c (B, T, in_channels) -> (B, 1, T*hop): norm, input conv, upsample stack, output conv, tanh
         (HiFiGAN.py:268-296)."""
         if self.stages == 1:
-            return _decode_common(self, self._decoder(), c, self.dim, self.hop)
+            return self._guarded(lambda c_: _decode_common(self, self._decoder(), c_, self.dim, self.hop), (c,), lambda: [self._decoder()], _frames_of(c, 1))
         for i in range(self.stages):
             c = self.decode_stage(i, c)
         return c
 
     def reset_buffer(self):
+        self.settle()
         for pr in self._programs().values():
             if pr is not None:
                 pr.reset()

@@ -63,7 +63,7 @@ class unguarded:
     per-step host synchronisations of the synchronous guard out; the guarded figure is reported beside them)."""
 
     def __init__(self, *ads):
-        self.gens = [g for a in ads for g in (a.tx_encoder, a.decoder)]
+        self.gens = [g for a in ads for g in (a.tx_encoder, a.rx_encoder, a.decoder) if g is not None]
 
     def __enter__(self):
         self.keep = [g.guard for g in self.gens]
@@ -1073,7 +1073,8 @@ def main():
                   "on, the default of AudioDec(...), for `value`: every program step of every batch is checked on the device and a split-f16 range "
                   "overflow is repaired by replay on the exact-f32 kernels -- deferred: the check of a batch is read (non-blocking) at the entry of a "
                   "later step, at most `guard_depth` batches are unverified (audiodec_amd/pipeline.py); `unguarded` = the same with guard=False, "
-                  "`guard_synchronous` = every program step checked before the next is issued (what direct calls of the facade do)"),
+                  "`guard_direct_calls` = direct calls of the facade in their default guard mode (checked when a result is first looked at: "
+                  "audiodec_amd/lazy_guard.py), `guard_synchronous` = every program step checked before the next is issued (ADK_GUARD_MODE=sync)"),
         "guard_depth": getattr(pipe, "depth", None) if NG == 1 else None,
         "guard_stats": ({"batches_verified": pipe.log.verified, "host_waits_for_the_oldest_batch": pipe.log.waits, "repairs": pipe.log.repairs}
                         if NG == 1 and getattr(pipe, "log", None) is not None else None),
@@ -1107,7 +1108,7 @@ def main():
         with unguarded(*ads):
             out["latency_ms"]["encode_decode_at_batch_median"] = batch_latency()
         if args.guard == "default":
-            out["latency_ms"]["encode_decode_at_batch_median_guarded"] = batch_latency()      # direct calls: every program step checked before the next
+            out["latency_ms"]["encode_decode_at_batch_median_guarded"] = batch_latency()      # direct calls with the default guard (lazy: checked when a result is looked at / by a later call)
 
     if rank == 0:
         # rank 0 prices its own GPU's kernels at every N (a few seconds); the legs below it are single-GPU extras
@@ -1210,22 +1211,49 @@ def main():
                             "regions_ms_per_step": [round(1e3 * e_ / ng, 4) for e_ in regions]}
                 out["unguarded"] = timed_pipeline(False, 4)
                 out["unguarded"]["what"] = "AudioDec(guard=False): the same workload and schedule with no per-step check (rounds 1-4 timed this as `value`)"
-                out["guard_synchronous"] = timed_pipeline(True, 0)
-                ad1g = build_single(True)
-                for _ in range(10):
-                    step(ad1g, x1)
-                torch.cuda.synchronize()
-                latg = []
-                for _ in range(50):
-                    t1 = time.perf_counter()
-                    step(ad1g, x1)
+
+                def single_stream_ms(ad1_):
+                    for _ in range(10):
+                        step(ad1_, x1)
                     torch.cuda.synchronize()
-                    latg.append(1e3 * (time.perf_counter() - t1))
-                out["guard_synchronous"].update({
-                    "single_stream_ms": round(float(np.median(latg)), 4), "single_stream_ms_min": round(float(np.min(latg)), 4),
-                    "what": "guard on, every program step checked before the next one is issued (adk_program_flags: one 1-thread kernel + one stream "
-                            "synchronisation per program and step): direct calls of the facade, and the pipeline with depth=0"})
+                    l_ = []
+                    for _ in range(50):
+                        t1 = time.perf_counter()
+                        step(ad1_, x1)
+                        torch.cuda.synchronize()
+                        l_.append(1e3 * (time.perf_counter() - t1))
+                    return round(float(np.median(l_)), 4), round(float(np.min(l_)), 4)
+                # direct calls of the drop-in surface (encode / quantize / lookup / decode, one after the other) in the DEFAULT guard mode of
+                # round 6 ("lazy", audiodec_amd/lazy_guard.py): the check of a call is posted behind it and read when its result is first looked
+                # at, or by a later call; here nothing looks (as the timed region of `value`): the calls of a batch go out on the pipeline object's
+                # three HIP streams with depth = 0, i.e. the pipeline's own deferred guard is OFF and the generators' call log does the work
+                out["guard_direct_calls"] = timed_pipeline(None, 0)
+                ad1g = build_single(None)
+                ss = single_stream_ms(ad1g)
+                lg_ = ad1g.tx_encoder._log
+                out["guard_direct_calls"].update({
+                    "single_stream_ms": ss[0], "single_stream_ms_min": ss[1],
+                    "mode": ad1g.tx_encoder.guard_mode, "calls_verified_single_stream": lg_.verified if lg_ is not None else None,
+                    "host_waits_single_stream": lg_.waits if lg_ is not None else None,
+                    "what": "guard on (AudioDec's default), direct calls: every program step posts its flag word behind it, results come back as GuardedTensor "
+                            "and are verified when first looked at (.cpu(), .to(), data_ptr(), any torch op) or by a later call; nothing waits per step"})
                 del ad1g
+                keep_mode = os.environ.get("ADK_GUARD_MODE")
+                os.environ["ADK_GUARD_MODE"] = "sync"              # read by the generators at construction
+                try:
+                    out["guard_synchronous"] = timed_pipeline(True, 0)
+                    ad1s = build_single(True)
+                    ss = single_stream_ms(ad1s)
+                    del ad1s
+                finally:
+                    if keep_mode is None:
+                        os.environ.pop("ADK_GUARD_MODE", None)
+                    else:
+                        os.environ["ADK_GUARD_MODE"] = keep_mode
+                out["guard_synchronous"].update({
+                    "single_stream_ms": ss[0], "single_stream_ms_min": ss[1],
+                    "what": "guard on, mode 'sync' (ADK_GUARD_MODE=sync: the direct-call guard of rounds 3-5): every program step checked before the next one is "
+                            "issued (adk_program_flags: one 1-thread kernel + one stream synchronisation per program and step)"})
             if not args.no_other_precision and NG == 1:
                 # the same workload through the other arithmetic (same weights, same inputs, same schedule)
                 other = "f32" if args.precision == "split16" else "split16"

@@ -338,11 +338,13 @@ def test_split16_overflow_raises_device_flag(gpu):
         assert flags.value == 0                          # sticky until read, then cleared
 
 
+@pytest.mark.parametrize("mode", ["lazy", "sync"])
 @pytest.mark.parametrize("model", ["vctk_v1", "vctk_sym"])
-def test_split16_range_overflow_is_repaired_by_the_f32_kernels(gpu, ckpt_root, model):
+def test_split16_range_overflow_is_repaired_by_the_f32_kernels(gpu, ckpt_root, model, mode):
     """The product default is the split-f16 arithmetic; its one failure mode -- an operand beyond the f16 range, |v| > 65504 --
-    must not cost a synchronous caller anything: with guard (AudioDec's default) the step that overflowed is repeated on the
-    exact-f32 kernels, in place, and the program stays on them.  Stream 1 of 3 is driven with audio scaled by 1e6 for one
+    must not cost a direct caller anything: with guard (AudioDec's default) the step that overflowed is repeated on the
+    exact-f32 kernels, in place, and the program stays on them.  Both guard modes of direct calls: "lazy" (default: the check is read
+    when the result is first looked at -- here `.cpu()` --, audiodec_amd/lazy_guard.py) and "sync" (before the call returns).  Stream 1 of 3 is driven with audio scaled by 1e6 for one
     frame in the middle of a stream (the encoder's first residual block then sees activations ~1e6) and the decoder is fed a
     zq scaled by 1e5 for one frame: no exception, a RuntimeWarning each, every frame before / during / after within tolerance
     of the CPU oracle (which is exact f32 throughout), the other streams undisturbed.  Audio scaled by 1e-6 (f16 subnormal
@@ -352,6 +354,9 @@ def test_split16_range_overflow_is_repaired_by_the_f32_kernels(gpu, ckpt_root, m
     B, hop, seed = 3, 300, 1337
     ad = load_audiodec(ckpt_root, model, seed, B, 1, True)
     assert ad.tx_encoder.guard and ad.decoder.guard and ad.tx_encoder.split16
+    for g_ in (ad.tx_encoder, ad.rx_encoder, ad.decoder):
+        g_.set_guard(True, mode)
+    from audiodec_amd import lazy_guard
     tx, rx, dec = build_oracle(model, B, seed)
     audio = np.stack([synth.synth_audio(55, s, 8 * hop) for s in range(B)])
     scale_x = {2: (1, 1e6), 5: (0, 1e-6)}            # frame -> (stream, factor)
@@ -367,11 +372,13 @@ def test_split16_range_overflow_is_repaired_by_the_f32_kernels(gpu, ckpt_root, m
             with warnings.catch_warnings(record=True) as w:
                 warnings.simplefilter("always")
                 z = ad.tx_encoder.encode(x.to(DEV))
+                assert (type(z) is lazy_guard.GuardedTensor) == (mode == "lazy")
+                zc = z.cpu()                                     # lazy: the first look at the result settles the log (and repairs)
             assert any(issubclass(i.category, RuntimeWarning) for i in w) == (f == 2), (f, [str(i.message) for i in w])
             oz = tx.encode(x)
             # (the stream that carried 1e6-sized samples keeps them in its state for a receptive field: its later, O(1) outputs
             # are differences of 1e6-sized f32 sums on either side -- tolerance 1e-3 there, 1e-4 everywhere else)
-            dz = (z.cpu() - oz).abs().amax(dim=(1, 2)) / oz.abs().amax(dim=(1, 2)).clamp(min=1.0)      # per stream, relative to its largest value
+            dz = (zc - oz).abs().amax(dim=(1, 2)) / oz.abs().amax(dim=(1, 2)).clamp(min=1.0)      # per stream, relative to its largest value
             tol = torch.full((B,), 1e-4); tol[1] = 1e-4 if f <= 2 else 1e-3
             assert bool((dz < tol).all()), (f, dz)
             oi = tx.quantize(oz)
@@ -381,11 +388,12 @@ def test_split16_range_overflow_is_repaired_by_the_f32_kernels(gpu, ckpt_root, m
             with warnings.catch_warnings(record=True) as w:
                 warnings.simplefilter("always")
                 y = ad.decoder.decode(zq.to(DEV))
+                yc = y.cpu()
             assert any(issubclass(i.category, RuntimeWarning) for i in w) == (f == 3), (f, [str(i.message) for i in w])
             oy = dec.decode(zq)
-            dy = (y.cpu() - oy).abs().amax(dim=(1, 2)) / oy.abs().amax(dim=(1, 2)).clamp(min=1.0)
+            dy = (yc - oy).abs().amax(dim=(1, 2)) / oy.abs().amax(dim=(1, 2)).clamp(min=1.0)
             tol = torch.full((B,), 1e-4); tol[2] = 1e-4 if f <= 3 else 1e-3
-            assert bool(torch.isfinite(y).all()) and bool((dy < tol).all()), (f, dy)
+            assert bool(torch.isfinite(yc).all()) and bool((dy < tol).all()), (f, dy)
             assert enc_prog.demoted == (f >= 2) and enc_prog.split16 == (f < 2)
             assert any(p.demoted for p in dec_progs) == (f >= 3)
     assert native.device_flags() == 0
