@@ -102,15 +102,16 @@ int launch_pack_split16(const float* w, float* out, int groups, int cout_g, int 
 int* flags_word();                                   // address of the sticky debug/error flags ON THE CURRENT DEVICE
 inline int* conv_err_word(const ConvArgs& a) { return a.err ? a.err : flags_word(); }
 constexpr int kMaxDevices = 64;
-// Per-device pool of sticky flag words (rvq.hip): every program owns one slot for its lifetime; each slot has a pinned, device-mapped
-// host mirror, so reading a word is one 1-thread kernel (atomic exchange -> host mirror) + a stream synchronisation, no copy.
-// `device` must be current.  flag_pool_fetch_all ORs and clears EVERY slot of the device (live programs or not: free slots are 0)
-// plus the device word, on the null stream, in one sweep -- it needs no list of programs and takes no lock programs wait for.
+// Per-device pool of sticky flag words (rvq.hip): every program owns one slot for its lifetime.  Since round 6 the words are PINNED HOST memory
+// mapped into the device: kernels atomicOr into them over the bus (failure paths only), the host reads and clears with one atomic exchange --
+// no kernel, no copy.  `device` must be current.  flag_pool_fetch waits for the stream first; flag_pool_take does not (the caller knows the
+// work has finished: an event); flag_pool_fetch_all ORs and clears EVERY slot of the device plus the device-wide word after a device
+// synchronisation -- it needs no list of programs and takes no lock programs wait for.
 int flag_pool_acquire(int device, int** word);
 void flag_pool_release(int device, int* word);
 int flag_pool_fetch(int device, int* word, hipStream_t s, int* v);
+int flag_pool_take(int device, int* word, int* v);
 int flag_pool_fetch_all(int device, int* acc);
-int flag_word_post(int* word, int* host_dev, hipStream_t s);      // 1-thread kernel: *host_dev (a device-mapped pinned host word) = atomicExch(word, 0); nothing waits
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kMaxDevices) ? d : 0; }
 // Makes `device` current for the lifetime of the object (programs are bound to the device they were created on,
 // whatever device the calling thread has current); restores the previous one.

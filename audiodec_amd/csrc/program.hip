@@ -280,8 +280,7 @@ struct adk_program {
     std::vector<char> seen;         // phase was run eagerly once (kernel attributes, symbol addresses are set up)
     std::vector<hipGraphExec_t> gexec;
     long long replays = 0, captures = 0;
-    // deferred flag checks (adk_program_flags_post / _poll): pinned host words + events of the last ADK_POST_SLOTS posts
-    int* post_host = nullptr; int* post_host_dev = nullptr;
+    // deferred flag checks (adk_program_flags_post / _poll): events of the last ADK_POST_SLOTS posts (the flag word itself is pinned host memory)
     hipEvent_t post_ev[ADK_POST_SLOTS] = {};
     long long post_next = 0;
 };
@@ -417,7 +416,6 @@ extern "C" void adk_program_destroy(adk_program* p) {
     flag_pool_release(p->device, p->flags);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->post_ev) if (e) (void)hipEventDestroy(e);
-    if (p->post_host) (void)hipHostFree(p->post_host);
     delete p;
 }
 
@@ -767,19 +765,11 @@ extern "C" int adk_program_flags(adk_program* p, void* stream, int32_t* out) {
 extern "C" int adk_program_flags_post(adk_program* p, void* stream, int64_t* ticket) {
     if (!p || !ticket) return fail(ADK_ERR_ARG, "program_flags_post: null argument");
     DeviceGuard guard(p->device);
-    if (!p->post_host) {
-        int* h = nullptr; int* hd = nullptr;
-        ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), ADK_POST_SLOTS * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));   // coherent: host visibility of a posted word must not depend on HIP_HOST_COHERENT
-        memset(h, 0, ADK_POST_SLOTS * sizeof(int));
-        ADK_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0));
-        p->post_host = h; p->post_host_dev = hd;
-    }
     const int slot = (int)(p->post_next % ADK_POST_SLOTS);
-    if (!p->post_ev[slot]) ADK_HIP_CHECK(hipEventCreateWithFlags(&p->post_ev[slot], hipEventDisableTiming | hipEventReleaseToSystem));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int rc = flag_word_post(p->flags, p->post_host_dev + slot, s);
-    if (rc != ADK_OK) return rc;
-    ADK_HIP_CHECK(hipEventRecord(p->post_ev[slot], s));
+    if (!p->post_ev[slot]) ADK_HIP_CHECK(hipEventCreateWithFlags(&p->post_ev[slot], hipEventDisableTiming));
+    // the post IS the event: the program's flag word is pinned host memory the kernels report into directly (rvq.hip: flag pool) -- once the
+    // event has completed, everything the step's launches had to say is in it.  (Rounds 4-5: a 1-thread kernel that moved a device word.)
+    ADK_HIP_CHECK(hipEventRecord(p->post_ev[slot], static_cast<hipStream_t>(stream)));
     *ticket = p->post_next++;
     return ADK_OK;
 }
@@ -799,8 +789,10 @@ extern "C" int adk_program_flags_poll(adk_program* p, int64_t ticket, int32_t bl
         if (e != hipSuccess) return fail(ADK_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
     }
     *done = 1;
-    *flags = reinterpret_cast<volatile int*>(p->post_host)[slot];
-    return ADK_OK;
+    int v = 0;
+    const int rc = flag_pool_take(p->device, p->flags, &v);       // read AND clear: what the program has reported up to now
+    *flags = v;
+    return rc;
 }
 
 extern "C" int adk_program_rewind(adk_program* p, int32_t frames) {

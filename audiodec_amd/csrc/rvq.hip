@@ -686,13 +686,16 @@ extern "C" int adk_ring_write(const float* src, adk_ring_view ring, const float*
 
 // ---- flag words ----------------------------------------------------------------------------------------------------
 namespace adk {
-// read AND clear in one atomic operation on the device: a bit set by a kernel of another HIP stream or host thread between a
-// separate read and a separate clear would be lost
-constexpr int kFlagSlots = 1024;          // programs alive at the same time on one device (slot 0: the sweep's result)
+// Round 6: a program's sticky flag word lives in PINNED HOST memory (coherent, mapped into the device); the kernels' rare failure paths
+// `atomicOr` into it across PCIe (system memory is uncached on the device side: an atomic op on the bus, which ROCm platforms support), and
+// the host reads AND clears it with one atomic exchange of its own -- no kernel, no copy.  Until round 5 the words lived in device memory and
+// every read was a 1-thread kernel (exchange -> pinned mirror, ~4 us on the device): one per program and step for the deferred guard, i.e.
+// three more launches per pipeline step than the work itself.  An event behind the step now IS the post (adk_program_flags_post).
+constexpr int kFlagSlots = 1024;          // programs alive at the same time on one device
 struct FlagPool {
-    int* dev = nullptr;                   // kFlagSlots words in device memory: what the kernels atomicOr into
-    volatile int* host = nullptr;         // kFlagSlots pinned host words, mapped into the device: where a fetch lands
-    int* host_dev = nullptr;              // ... their device-side address
+    int* host = nullptr;                  // kFlagSlots pinned host words: what the kernels atomicOr into, what the host exchanges
+    int* host_dev = nullptr;              // ... their device-side address (what a program's launches are given)
+    int* sweep_dev = nullptr;             // one device word + its pinned mirror slot 0: adk_debug_flags' read of the DEVICE-wide word (op-level calls)
     std::vector<int> free_slots;
     int next = 1;
 };
@@ -700,14 +703,12 @@ static FlagPool g_pool[kMaxDevices];
 static std::mutex g_pool_mu;              // slot bookkeeping only: never held across a device synchronisation
 
 static int pool_ready(FlagPool& fp) {     // (g_pool_mu held, the pool's device current)
-    if (fp.dev) return ADK_OK;
-    int* d = nullptr; int* h = nullptr; int* hd = nullptr;
-    ADK_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d), kFlagSlots * sizeof(int)));
-    ADK_HIP_CHECK(hipMemset(d, 0, kFlagSlots * sizeof(int)));
+    if (fp.host) return ADK_OK;
+    int* h = nullptr; int* hd = nullptr;
     ADK_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h), kFlagSlots * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     memset(h, 0, kFlagSlots * sizeof(int));
     ADK_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0));
-    fp.dev = d; fp.host = h; fp.host_dev = hd;
+    fp.host = h; fp.host_dev = hd;
     return ADK_OK;
 }
 
@@ -720,50 +721,41 @@ int flag_pool_acquire(int device, int** word) {
     if (!fp.free_slots.empty()) { slot = fp.free_slots.back(); fp.free_slots.pop_back(); }
     else if (fp.next < kFlagSlots) slot = fp.next++;
     else return fail(ADK_ERR_STATE, "more than 1023 live programs on one device");
-    *word = fp.dev + slot;
+    __atomic_store_n(fp.host + slot, 0, __ATOMIC_RELEASE);
+    *word = fp.host_dev + slot;
     return ADK_OK;
+}
+
+static int* pool_host_word(FlagPool& fp, const int* word) {
+    if (!fp.host_dev || word <= fp.host_dev || word >= fp.host_dev + kFlagSlots) return nullptr;
+    return fp.host + (word - fp.host_dev);
 }
 
 void flag_pool_release(int device, int* word) {
     if (!word) return;
-    (void)hipMemset(word, 0, sizeof(int));           // (a released slot reads 0 in the sweep)
     std::lock_guard<std::mutex> lk(g_pool_mu);
     FlagPool& fp = g_pool[device];
-    if (fp.dev && word > fp.dev && word < fp.dev + kFlagSlots) fp.free_slots.push_back((int)(word - fp.dev));
+    int* h = pool_host_word(fp, word);
+    if (!h) return;
+    __atomic_store_n(h, 0, __ATOMIC_RELEASE);          // (a released slot reads 0 in the sweep)
+    fp.free_slots.push_back((int)(h - fp.host));
 }
 
-__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); __threadfence_system(); }
-
-int flag_word_post(int* word, int* host_dev, hipStream_t s) {
-    if (!word || !host_dev) return fail(ADK_ERR_ARG, "flag_word_post: null pointer");
-    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, s, word, host_dev);
-    ADK_HIP_CHECK(hipGetLastError());
+// read AND clear in one atomic operation: a bit set by a kernel of another HIP stream between a separate read and a separate clear would be lost
+int flag_pool_take(int device, int* word, int* v) {
+    FlagPool& fp = g_pool[device];
+    int* h = pool_host_word(fp, word);
+    if (!h) return fail(ADK_ERR_ARG, "flag word outside the device's pool");
+    *v = __atomic_exchange_n(h, 0, __ATOMIC_ACQ_REL);
     return ADK_OK;
 }
 
 int flag_pool_fetch(int device, int* word, hipStream_t s, int* v) {
-    FlagPool& fp = g_pool[device];
-    if (!fp.dev || word <= fp.dev || word >= fp.dev + kFlagSlots) return fail(ADK_ERR_ARG, "flag word outside the device's pool");
-    const int slot = (int)(word - fp.dev);
-    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, s, word, fp.host_dev + slot);
-    ADK_HIP_CHECK(hipGetLastError());
-    ADK_HIP_CHECK(hipStreamSynchronize(s));
-    *v = fp.host[slot];
-    return ADK_OK;
+    ADK_HIP_CHECK(hipStreamSynchronize(s));            // what was queued on the stream has reported
+    return flag_pool_take(device, word, v);
 }
 
-__global__ void flags_sweep_kernel(int* pool, int n, int* out) {
-    __shared__ int acc;
-    if (threadIdx.x == 0) acc = 0;
-    __syncthreads();
-    int v = 0;
-    if (pool)
-        for (int i = 1 + threadIdx.x; i < n; i += blockDim.x)
-            if (pool[i]) v |= atomicExch(&pool[i], 0);
-    if (v) atomicOr(&acc, v);
-    __syncthreads();
-    if (threadIdx.x == 0) *out = acc | atomicExch(&g_adk_flags, 0);
-}
+__global__ void word_fetch_clear_kernel(int* word, int* out) { *out = atomicExch(word, 0); __threadfence_system(); }
 
 int flag_pool_fetch_all(int device, int* acc) {
     FlagPool& fp = g_pool[device];
@@ -773,10 +765,13 @@ int flag_pool_fetch_all(int device, int* acc) {
         if (rc != ADK_OK) return rc;
     }
     ADK_HIP_CHECK(hipDeviceSynchronize());             // everything queued on the device has reported
-    hipLaunchKernelGGL(flags_sweep_kernel, dim3(1), dim3(256), 0, nullptr, fp.dev, kFlagSlots, fp.host_dev);
+    for (int i = 1; i < kFlagSlots; ++i)
+        if (__atomic_load_n(fp.host + i, __ATOMIC_ACQUIRE)) *acc |= __atomic_exchange_n(fp.host + i, 0, __ATOMIC_ACQ_REL);
+    // the device-wide word (launches that belong to no program) is device memory: one 1-thread kernel moves it to slot 0 of the pinned words
+    hipLaunchKernelGGL(word_fetch_clear_kernel, dim3(1), dim3(1), 0, nullptr, flags_word(), fp.host_dev);
     ADK_HIP_CHECK(hipGetLastError());
     ADK_HIP_CHECK(hipStreamSynchronize(nullptr));
-    *acc |= fp.host[0];
+    *acc |= __atomic_exchange_n(fp.host, 0, __ATOMIC_ACQ_REL);
     return ADK_OK;
 }
 
@@ -788,7 +783,7 @@ extern "C" int adk_debug_flags(int32_t* out) {
     int all = 0;
     const int here = current_device();
     for (int d = 0; d < kMaxDevices; ++d) {
-        if (!g_flag_ptr[d] && !g_pool[d].dev && d != here) continue;
+        if (!g_flag_ptr[d] && !g_pool[d].host && d != here) continue;
         DeviceGuard guard(d);
         const int rc = flag_pool_fetch_all(d, &all);
         if (rc != ADK_OK) return rc;

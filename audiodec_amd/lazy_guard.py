@@ -124,14 +124,17 @@ class CallLog:
         with self.lock:
             while self.pending:
                 c = self.pending[0]
-                flags = 0
+                found = []
                 for prog, _frames, ticket in c.steps:
                     done, fl = prog.poll_flags(ticket, block)
                     if not done:
+                        if found:
+                            break                            # (what was read is gone from the word: handle it now)
                         return False
-                    flags |= fl
-                if flags:
-                    self._recover()
+                    if fl:
+                        found.append((prog, fl))
+                if found:
+                    self._recover(found)
                     return True
                 self.pending.popleft()
                 self.verified += 1
@@ -189,26 +192,28 @@ class CallLog:
             return GuardedTensor.wrap(out, self)
 
     # ---- repair ----
-    def _recover(self):
+    def _recover(self, found):
+        """found: [(program, flags)] read from posts of the OLDEST unverified call, in issue order: that call is the first bad one.  (A poll
+        reads AND clears the program's word -- ABI 14 --, so what collect() read is handed on; a word may already hold what a later call's
+        step reported: the blame can only be early, and everything from the blamed call on is repeated.)"""
         self._drain()                                        # everything issued has finished: every post can be read
         calls = list(self.pending)
-        first, culprit, by_prog = None, None, {}
-        for i, c in enumerate(calls):
+        first, culprit, by_prog = 0, found[0][0], {}
+        for prog, fl in found:
+            by_prog[prog] = by_prog.get(prog, 0) | fl
+        for c in calls:                                      # the rest of the words: read (and thereby cleared) too
             for prog, _f, ticket in c.steps:
                 _done, fl = prog.poll_flags(ticket, True)
                 if fl:
                     by_prog[prog] = by_prog.get(prog, 0) | fl
-                    if first is None:
-                        first, culprit = i, prog
         self.pending.clear()
         other = 0
         for fl in by_prog.values():
             other |= fl & ~native.FLAG_F16_OVERFLOW
         native.raise_for_flags(other, "guarded call")
-        if first is None:
+        if not (by_prog.get(culprit, 0) & native.FLAG_F16_OVERFLOW):
             self.verified += len(calls)
             return
-        self.verified += first
         redo = calls[first:]
         for c in reversed(redo):
             for prog, frames, _t in reversed(c.steps):

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB_PATH") or os.path.join(_HERE, "libaudiodec_hip.so")   # override: tuning builds only
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 ADK_OK = 0
 ACT_NONE, ACT_ELU, ACT_LEAKY, ACT_TANH = 0, 1, 2, 3

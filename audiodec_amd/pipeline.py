@@ -87,7 +87,7 @@ class GuardLog:
         while self.pending:
             must = block or len(self.pending) >= self.depth or (self.budget is not None and self.units_pending() + incoming > self.budget)
             b = self.pending[0]
-            flags, ready = 0, True
+            found, ready = [], True
             for prog, _frames, ticket in b.steps:
                 done, fl = self._poll(prog, ticket, False)
                 if not done and must:
@@ -96,30 +96,33 @@ class GuardLog:
                 if not done:
                     ready = False
                     break
-                flags |= fl
-            if not ready:
+                if fl:
+                    found.append((prog, fl))
+            if found:
+                # (a poll reads AND clears the program's word -- ABI 14 --, so what was found is handed on; the posts of the head batch that were
+                # not reached are read by _recover.  A word may already hold what a LATER batch's step reported: the blame can only be early.)
+                self._recover(found)
                 return
-            if flags:
-                self._recover()
+            if not ready:
                 return
             self.pending.popleft()
             self.verified += 1
 
-    def _recover(self):
+    def _recover(self, found):
+        """found: [(program, flags)] read from posts of the OLDEST unverified batch, in issue order: that batch is the first bad one."""
         self._drain()                                   # everything issued has finished: every post can be read
         batches = list(self.pending)
-        by_prog, first, culprit = {}, None, None
-        for i, b in enumerate(batches):
+        by_prog, culprit = {}, found[0][0]
+        for prog, fl in found:
+            by_prog[prog] = by_prog.get(prog, 0) | fl
+        for b in batches:                               # the rest of the words: read (and thereby cleared) too
             for prog, _frames, ticket in b.steps:
-                done, fl = self._poll(prog, ticket, True)
+                _done, fl = self._poll(prog, ticket, True)
                 if fl:
                     by_prog[prog] = by_prog.get(prog, 0) | fl
-                    if first is None:
-                        first, culprit = i, prog
         self.pending.clear()
-        self.verified += first
-        self._repair(batches[first:], by_prog, culprit)
-        self.verified += len(batches) - first
+        self._repair(batches, by_prog, culprit)
+        self.verified += len(batches)
         self.repairs += 1
 
 

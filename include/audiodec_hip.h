@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ADK_ABI_VERSION 13
+#define ADK_ABI_VERSION 14
 
 enum { ADK_OK = 0, ADK_ERR_ARG = -1, ADK_ERR_SHAPE = -2, ADK_ERR_HIP = -3, ADK_ERR_STATE = -4 };
 
@@ -297,13 +297,14 @@ int adk_program_reset(adk_program* p, void* stream);
  * it exactly; audiodec_amd/stream_generator.py does that automatically for synchronous callers ("guard"). */
 int adk_program_flags(adk_program* p, void* stream, int32_t* out);
 int adk_program_rewind(adk_program* p, int32_t frames);
-/* The DEFERRED form of adk_program_flags, for callers that keep several steps in flight (audiodec_amd/pipeline.py).
- * adk_program_flags_post enqueues, behind the launches of the step(s) just issued on `stream`, one 1-thread kernel that exchanges the
- * program's word for 0 and stores the old value in a pinned host word of this post, followed by an event; nothing waits.  *ticket
- * names the post (tickets count up from 0; the host words of the last ADK_POST_SLOTS posts are kept).
- * adk_program_flags_poll(ticket, block): *done = 1 and *flags = that word once the event has completed (block != 0: wait for it),
- * else *done = 0.  ADK_ERR_STATE for a ticket that was never issued or whose slot has been reused.  A word covers what the program's
- * launches reported between the previous post (or adk_program_flags) and this one. */
+/* The DEFERRED form of adk_program_flags, for callers that keep several steps in flight (audiodec_amd/pipeline.py, lazy_guard.py).
+ * adk_program_flags_post records an event behind the launches of the step(s) just issued on `stream`; nothing waits, nothing is launched
+ * (ABI 14: a program's flag word is pinned host memory its kernels report into directly; ABI 13 launched a 1-thread kernel per post).  *ticket
+ * names the post (tickets count up from 0; the events of the last ADK_POST_SLOTS posts are kept).
+ * adk_program_flags_poll(ticket, block): once the event has completed (block != 0: wait for it) *done = 1 and *flags = the program's word,
+ * read AND cleared; else *done = 0.  ADK_ERR_STATE for a ticket that was never issued or whose slot has been reused.  With several steps of
+ * one program in flight a word may already hold what a LATER step reported: a failure is attributed to the polled step or an earlier
+ * one, never to a later one -- a caller that repairs by rewinding from the step a poll blames (and everything after it) is exact. */
 enum { ADK_POST_SLOTS = 32 };
 int adk_program_flags_post(adk_program* p, void* stream, int64_t* ticket);
 int adk_program_flags_poll(adk_program* p, int64_t ticket, int32_t block, int32_t* done, int32_t* flags);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""N host-synchronised single-stream steps of vctk_v1 (guard off, the facade's default lowering) between two bench.py-style marker launches:
+"""N host-synchronised single-stream steps of vctk_v1 (the facade's default lowering; guard: ADK_SS_GUARD = off (default) | lazy | sync) between two bench.py-style marker launches:
 run under `rocprofv3 --kernel-trace` and summarise with tools/trace_summary.py to split a step's latency into kernel time and gaps.
 usage: single_stream_steps.py [streams=1] [steps=40]"""
 import os, sys, time, tempfile
@@ -15,7 +15,10 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 dev = torch.device("cuda:0")
 root = tempfile.mkdtemp()
 synth.write_model(root, bench.MODEL, bench.SEED)
-ad = bench.build_audiodec(root, dev, B, 1, guard=False)
+G = os.environ.get("ADK_SS_GUARD", "off")
+if G == "sync":
+    os.environ["ADK_GUARD_MODE"] = "sync"
+ad = bench.build_audiodec(root, dev, B, 1, guard=(False if G == "off" else True))
 x = torch.from_numpy(np.stack([synth.synth_audio(5, s, bench.HOP) for s in range(B)]))[:, None, :].to(dev)
 with torch.no_grad():
     for _ in range(20):
@@ -29,4 +32,5 @@ with torch.no_grad():
         torch.cuda.synchronize()
         lat.append(1e3 * (time.perf_counter() - t0))
     torch.arange(bench.PMC_MARKER_N, device=dev); torch.cuda.synchronize()
+print(f"guard {G}: ", end="")
 print(f"streams {B}: median {np.median(lat):.4f} ms, min {np.min(lat):.4f} ms per host-synchronised step ({N} steps)")
