@@ -519,3 +519,4 @@ def test_shadow_rings_are_bit_identical(gpu, ckpt_root, monkeypatch, model, B, m
         assert torch.equal(i1, i0), f"call {k}: indices differ"
         assert torch.equal(y1, y0), f"call {k}: waveform differs by {float((y1 - y0).abs().max()):.3e}"
     assert native.device_flags() == 0
+
