@@ -58,7 +58,7 @@
 #define ADK_SK_OWNER_LATE 1 // 1: with two workgroups per tile, the later-dispatched blocks of an XCD take the owner halves
 #endif
 #ifndef ADK_SK16_DBG
-#define ADK_SK16_DBG 0      // tuning experiments only: 1 = lo part not computed, 2 = no input activation
+#define ADK_SK16_DBG 0      // tuning experiments only: 1 = lo part not computed, 2 = no input activation, 64 = half of the waves load no weights (knock-out)
 #endif
 
 namespace adk {
@@ -563,7 +563,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN == 4) ? 2 : 1) void conv
             constexpr int RPS = RB / 4;
             const bool has_next2 = (it + 2 < n_units);
             const unsigned char* Bh = reinterpret_cast<const unsigned char*>(Bb);
+#if ADK_SK16_DBG & 64
+            // knock-out (results are garbage): the waves with wn == 1 request no weight fragments at all -- what would the launch cost if the two
+            // waves of a workgroup that multiply the SAME 32 rows shared one copy of their A fragments (half the A traffic)?
+            const unsigned sa = (has_next && wn == 0) ? w_base + (unsigned)w_kc * 8192u : 0xfff00000u;
+#else
             const unsigned sa = has_next ? w_base + (unsigned)w_kc * 8192u : 0xfff00000u;
+#endif
             const bool k_ok = has_next2 && t_tap < a.taps;
             const unsigned cb = (unsigned)t_cblk * 128u;
             __builtin_amdgcn_sched_barrier(0);
