@@ -29,12 +29,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak; a split-f16 product sum issues 3 of them
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_MARKER_N = 7654321                         # --pmc-markers: element count of the marker launches
-PMC_TRAFFIC_FILE = "r5_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, pipelined schedule (tools/profile_round.sh)
-STEADY_STATS_FILE = "r5_kernel_stats_steady.csv"   # rocprofv3 --kernel-trace over the timed steps of the same schedule (tools/trace_summary.py)
-SERIAL_STATS_FILE = "r5_kernel_stats_serial.csv"   # ... of `bench.py --serial` (one HIP stream, nothing else on the chip)
+PMC_TRAFFIC_FILE = "r6_pmc_traffic.csv"        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this bench, pipelined schedule (tools/profile_round.sh)
+STEADY_STATS_FILE = "r6_kernel_stats_steady.csv"   # rocprofv3 --kernel-trace over the timed steps of the same schedule (tools/trace_summary.py)
+SERIAL_STATS_FILE = "r6_kernel_stats_serial.csv"   # ... of `bench.py --serial` (one HIP stream, nothing else on the chip)
 PMC_TRAFFIC_SCRIPT = "tools/profile_round.sh"
 # the same three captures of `bench.py --frames-per-step 5` (the reference streamer's default chunk): the secondary roofline of the named kernel
-T5_STEADY_STATS_FILE, T5_SERIAL_STATS_FILE, T5_PMC_TRAFFIC_FILE = "r5_kernel_stats_T5_steady.csv", "r5_kernel_stats_T5_serial.csv", "r5_pmc_traffic_T5.csv"
+T5_STEADY_STATS_FILE, T5_SERIAL_STATS_FILE, T5_PMC_TRAFFIC_FILE = "r6_kernel_stats_T5_steady.csv", "r6_kernel_stats_T5_serial.csv", "r6_pmc_traffic_T5.csv"
 
 def build_audiodec(root, device, streams, max_frames, model=None, guard=None):
     from audiodec_amd import synth

@@ -35,7 +35,7 @@ if [ "$what" = "all" ] || [ "$what" = "T5" ]; then
   # T5: the same captures at the reference streamer's default chunk (5 frames per stream per call, demoStream.py:28) -- where the north-star's
   # named kernel runs as conv_up16 on 5x the rows: <tag>_kernel_stats_T5_{steady,serial}.csv, <tag>_pmc_traffic_T5.csv
   export ADK_PROFILE_CONFIG="streams=256 stages=2 frames_per_step=5 precision=split16 guard=default rvq=${ADK_BENCH_RVQ:-tx}"
-  S5=16
+  S5=100   # (the in-step figure of the 5-frames-per-call kernel from >= 100 launches, not 16)
   A5="--frames-per-step 5 --steps $S5 --warmup 6 --preroll 16 --pmc-markers --no-cpu-baseline --no-other-precision --no-op-profile --no-extra-configs --no-self-check --no-guarded --no-t5"
   mkdir -p $R/gpurun_out/${tag}_T5
   timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${tag}_T5/trace -o p --output-format csv -- python $R/bench.py $A5 > $R/gpurun_out/${tag}_T5_trace.log 2>&1
