@@ -188,7 +188,7 @@ def _rocprof_name(dom):
     if m:
         return ("conv_up16_kernel<",)
     if dom.startswith("conv_ou16<"):
-        return ("conv_ou16_kernel<",)
+        return ("conv_ou16_",)                       # conv_ou16_dma_kernel<ACT, MT2> since round 6 (conv_ou16_kernel<...> before)
     return None
 
 
@@ -846,6 +846,7 @@ def finish_line(out):
         "guard_every_step_synchronised": g(out, "guard_synchronous", "value"), "exact_f32": g(out, "other_precision", "value"),
         "latency_ms": {"single_stream": g(lat, "encode_decode_single_stream_median"), "single_stream_guarded_direct_calls": g(out, "guard_direct_calls", "single_stream_ms"),
                        "single_stream_guard_synchronised": g(out, "guard_synchronous", "single_stream_ms"),
+                       "single_stream_unguarded_same_loop": g(out, "guard_direct_calls", "single_stream_ms_unguarded_same_loop"),
                        "batch": g(lat, "encode_decode_at_batch_median"), "batch_guarded_direct_calls": g(lat, "encode_decode_at_batch_median_guarded"),
                        "cfg2_encoder_rvq_32_streams": g(out, "extra_configs", "cfg2_vctk_encoder_rvq_B32", "ms_per_step"),
                        "cfg3_sym_codec_64_streams": g(out, "extra_configs", "cfg3_vctk_sym_full_B64", "ms_per_step"),
@@ -854,7 +855,8 @@ def finish_line(out):
                      "traffic_bytes_per_launch": roof.get("traffic"), "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch")},
         "north_star_kernel": {"kernel": ct.get("kernel"), "frac_of_8TBs": ct.get("frac"), "frac_serial": ct.get("frac_serial"), "avg_launch_us_serial": ct.get("avg_launch_us_serial"), "frac_events_serial": ct.get("frac_events_serial"),
                               "T5_frac_serial": t5.get("frac_serial"), "T5_frac": t5.get("frac")},
-        "launches_per_step": roof.get("launches_per_step_all_kernels"),
+        "launches_per_step": (roof.get("launches_per_step_all_kernels") + 2) if roof.get("launches_per_step_all_kernels") else None,      # program launches + RVQ search + lookup (no guard-post kernels since ABI 14)
+        "north_star_kernel_launch_us": {"serial": ct.get("avg_launch_us_serial"), "pipelined": ct.get("avg_launch_us_pipelined")},
         "self_check_ok": g(out, "self_check", "ok"), "device_error_flags": out.get("device_error_flags"),
     }
     return out
@@ -1212,48 +1214,61 @@ def main():
                 out["unguarded"] = timed_pipeline(False, 4)
                 out["unguarded"]["what"] = "AudioDec(guard=False): the same workload and schedule with no per-step check (rounds 1-4 timed this as `value`)"
 
-                def single_stream_ms(ad1_):
+                # single stream in the three guard modes, INTERLEAVED (five rounds of 20 host-synchronised steps per model, median over all): models
+                # measured one after the other differed by +-25 us from run to run (clock / allocator state), more than the guard costs
+                def build_mode(mode):
+                    keep_mode = os.environ.get("ADK_GUARD_MODE")
+                    if mode == "sync":
+                        os.environ["ADK_GUARD_MODE"] = "sync"          # read by the generators at construction
+                    try:
+                        return build_single(False if mode == "off" else True)
+                    finally:
+                        if keep_mode is None:
+                            os.environ.pop("ADK_GUARD_MODE", None)
+                        else:
+                            os.environ["ADK_GUARD_MODE"] = keep_mode
+                singles = {m_: build_mode(m_) for m_ in ("off", "lazy", "sync")}
+                lat_m = {m_: [] for m_ in singles}
+                for a_ in singles.values():
                     for _ in range(10):
-                        step(ad1_, x1)
-                    torch.cuda.synchronize()
-                    l_ = []
-                    for _ in range(50):
-                        t1 = time.perf_counter()
-                        step(ad1_, x1)
-                        torch.cuda.synchronize()
-                        l_.append(1e3 * (time.perf_counter() - t1))
-                    return round(float(np.median(l_)), 4), round(float(np.min(l_)), 4)
+                        step(a_, x1)
+                torch.cuda.synchronize()
+                for _ in range(5):
+                    for m_, a_ in singles.items():
+                        for _ in range(20):
+                            t1 = time.perf_counter()
+                            step(a_, x1)
+                            torch.cuda.synchronize()
+                            lat_m[m_].append(1e3 * (time.perf_counter() - t1))
+                ss = {m_: (round(float(np.median(v_)), 4), round(float(np.min(v_)), 4)) for m_, v_ in lat_m.items()}
+                lg_ = singles["lazy"].tx_encoder._log
                 # direct calls of the drop-in surface (encode / quantize / lookup / decode, one after the other) in the DEFAULT guard mode of
                 # round 6 ("lazy", audiodec_amd/lazy_guard.py): the check of a call is posted behind it and read when its result is first looked
-                # at, or by a later call; here nothing looks (as the timed region of `value`): the calls of a batch go out on the pipeline object's
+                # at, or by a later call; here nothing looks (as in the timed region of `value`): the calls of a batch go out on the pipeline object's
                 # three HIP streams with depth = 0, i.e. the pipeline's own deferred guard is OFF and the generators' call log does the work
                 out["guard_direct_calls"] = timed_pipeline(None, 0)
-                ad1g = build_single(None)
-                ss = single_stream_ms(ad1g)
-                lg_ = ad1g.tx_encoder._log
                 out["guard_direct_calls"].update({
-                    "single_stream_ms": ss[0], "single_stream_ms_min": ss[1],
-                    "mode": ad1g.tx_encoder.guard_mode, "calls_verified_single_stream": lg_.verified if lg_ is not None else None,
+                    "single_stream_ms": ss["lazy"][0], "single_stream_ms_min": ss["lazy"][1], "single_stream_ms_unguarded_same_loop": ss["off"][0],
+                    "mode": singles["lazy"].tx_encoder.guard_mode, "calls_verified_single_stream": lg_.verified if lg_ is not None else None,
                     "host_waits_single_stream": lg_.waits if lg_ is not None else None,
-                    "what": "guard on (AudioDec's default), direct calls: every program step posts its flag word behind it, results come back as GuardedTensor "
-                            "and are verified when first looked at (.cpu(), .to(), data_ptr(), any torch op) or by a later call; nothing waits per step"})
-                del ad1g
+                    "what": "guard on (AudioDec's default), direct calls: every program step posts an event behind it, results come back as GuardedTensor "
+                            "and are verified when first looked at (.cpu(), .to(), data_ptr(), any torch op) or by a later call; nothing waits per step.  "
+                            "single_stream_ms*: one-stream models in the three guard modes measured interleaved (5 x 20 host-synchronised steps each)"})
+                del singles
                 keep_mode = os.environ.get("ADK_GUARD_MODE")
                 os.environ["ADK_GUARD_MODE"] = "sync"              # read by the generators at construction
                 try:
                     out["guard_synchronous"] = timed_pipeline(True, 0)
-                    ad1s = build_single(True)
-                    ss = single_stream_ms(ad1s)
-                    del ad1s
                 finally:
                     if keep_mode is None:
                         os.environ.pop("ADK_GUARD_MODE", None)
                     else:
                         os.environ["ADK_GUARD_MODE"] = keep_mode
+                ss = (ss["sync"][0], ss["sync"][1])
                 out["guard_synchronous"].update({
                     "single_stream_ms": ss[0], "single_stream_ms_min": ss[1],
                     "what": "guard on, mode 'sync' (ADK_GUARD_MODE=sync: the direct-call guard of rounds 3-5): every program step checked before the next one is "
-                            "issued (adk_program_flags: one 1-thread kernel + one stream synchronisation per program and step)"})
+                            "issued (adk_program_flags: one stream synchronisation + one host-side exchange of the flag word per program and step)"})
             if not args.no_other_precision and NG == 1:
                 # the same workload through the other arithmetic (same weights, same inputs, same schedule)
                 other = "f32" if args.precision == "split16" else "split16"
