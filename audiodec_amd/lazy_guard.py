@@ -47,6 +47,9 @@ MAX_PENDING = 64          # calls a log keeps unverified at most (entries withou
 def plain(t):
     """The ordinary tensor behind a GuardedTensor (same storage), WITHOUT settling its log; anything else as it is."""
     if type(t) is GuardedTensor:
+        p = t.__dict__.get("_adk_plain")
+        if p is not None:
+            return p
         with torch._C.DisableTorchFunctionSubclass():
             return t.as_subclass(torch.Tensor)
     return t
@@ -75,6 +78,7 @@ class GuardedTensor(torch.Tensor):
     def wrap(t, log):
         g = torch.Tensor._make_subclass(GuardedTensor, t)
         g.__dict__["_adk_log"] = log
+        g.__dict__["_adk_plain"] = t            # (what the kernels wrote into: handing a result on to the next call costs a dict lookup)
         return g
 
     @classmethod
