@@ -353,9 +353,8 @@ def test_fused_residual_units_are_bit_identical(gpu, ckpt_root, model, B, max_fr
             idx = ad_f.tx_encoder.quantize(zf)
             yf = ad_f.decoder.decode(ad_f.rx_encoder.lookup(idx)); yu = ad_u.decoder.decode(ad_u.rx_encoder.lookup(idx))
             # (vctk_v1: conv_out + the last up-sampler as ONE launch runs on 16 x 16 x 32 MFMAs since round 6 -- the same products and chunk order as
-            # the two-launch form on 32 x 32 x 16, another grouping of the f32 additions inside an instruction: f32 round-off, not bit-identity;
-            # ADK_OU16_V=2 selects the four-wave form, which is bit-identical)
-            if model == "vctk_v1" and os.environ.get("ADK_OU16_V", "3") != "2":
+            # the two-launch form on 32 x 32 x 16, another grouping of the f32 additions inside an instruction: f32 round-off, not bit-identity)
+            if model == "vctk_v1":
                 assert float((yf - yu).abs().max()) < 2e-6, (i, float((yf - yu).abs().max()))
             else:
                 assert torch.equal(yf, yu), i
