@@ -403,6 +403,9 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
     for name, n in want.items():
         assert kf.count(name) >= n, (name, kf)
     assert not any("rb16" in k or "fused" in k or "unit" in k for k in ku), ku
+    # conv_out + the last up-sampler as one launch (conv_ou16, 16 x 16 x 32 MFMAs since round 6) against the two-launch form on 32 x 32 x 16: the
+    # same products in the same chunk order, another grouping of the f32 additions inside an instruction -- the waveform agrees to f32 round-off
+    ou16 = any("conv_ou16" in pr.describe_op(i, f) for pr in progs_f for i in range(pr.n_ops) for f in {1, max_frames})     # (a short step may fuse what a full one does not)
     frames = [max_frames, max_frames, 1, max_frames, max_frames, 1, max_frames, max_frames, max_frames] if max_frames > 1 else [1] * 9
     maxc = [64, 64, 0, 64, 64, 64, 128, 128, 64]               # chain_max_channels of the fused model per call
     audio = np.stack([synth.synth_audio(91, s % 5, sum(frames) * hop) for s in range(B)])
@@ -434,8 +437,10 @@ def test_residual_chains_are_bit_identical(gpu, ckpt_root, model, B, max_frames,
                 yf = ad_f.decoder.decode(ad_f.rx_encoder.lookup(idx))
                 native.set_option("chain_max_channels", 0)
                 yu = ad_u.decoder.decode(ad_u.rx_encoder.lookup(idx))
-                if exact:
+                if exact and not ou16:
                     assert torch.equal(yf, yu), (i, float((yf - yu).abs().max()))
+                elif exact:
+                    assert float((yf - yu).abs().max()) < 2e-6, (i, float((yf - yu).abs().max()))
                 else:
                     assert float((yf - yu).abs().max()) < 2e-5, (i, float((yf - yu).abs().max()))
     finally:

@@ -589,7 +589,9 @@ def test_chunked_equals_one_shot_and_reset(gpu, ckpt_root):
 def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16, stages):
     """set_stages(2): the vocoder as two programs (cut in front of upsample stage 2) gives bit-identical output,
     back to back or with the halves on different HIP streams (v1: grouped convs + 1x1; v0: three residual blocks
-    averaged into the hand-over buffer)."""
+    averaged into the hand-over buffer).  A cut in front of stage 3 separates the two convs that conv_ou16 runs as one
+    launch on 16 x 16 x 32 MFMAs; the two-launch form sums the same products in the same chunk order on 32 x 32 x 16:
+    f32 round-off there, not bit-identity."""
     seed, B, hop = 99, 3, 300
     audio = np.stack([synth.synth_audio(seed, s, 4 * hop) for s in range(B)])
     ad1 = load_audiodec(ckpt_root, model, seed, B, 2, split16)
@@ -601,6 +603,10 @@ def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16, stag
     n_st = 2 if stages == "2" else len(stages.split(",")) + 1
     assert ad1.decoder.stages == 1 and ad2.decoder.stages == n_st and len(ad2.decoder._decoder_stages()) == n_st
     s2 = torch.cuda.Stream(gpu)
+    splits_ou16 = split16 and "3" in stages.split(",")
+
+    def same(a, b):
+        return a.shape == b.shape and (float((a - b).abs().max()) < 2e-6 if splits_ou16 else torch.equal(a, b))
     for f0, f1 in ((0, 1), (1, 3), (3, 4)):
         x = torch.from_numpy(audio[:, f0 * hop:f1 * hop])[:, None, :].to(gpu)
         zq = ad1.rx_encoder.lookup(ad1.tx_encoder.quantize(ad1.tx_encoder.encode(x)))
@@ -617,12 +623,12 @@ def test_two_stage_vocoder_equals_one_stage(gpu, ckpt_root, model, split16, stag
             torch.cuda.current_stream().wait_stream(s2)
         else:
             y2 = ad2.decoder.decode(zq)
-        assert y1.shape == y2.shape and torch.equal(y1, y2)
+        assert same(y1, y2)
     ad2.decoder.reset_stream(1)                              # per-stream reset reaches both programs
     ad1.decoder.reset_stream(1)
     x = torch.from_numpy(audio[:, :hop])[:, None, :].to(gpu)
     zq = ad1.rx_encoder.lookup(ad1.tx_encoder.quantize(ad1.tx_encoder.encode(x)))
-    assert torch.equal(ad1.decoder.decode(zq), ad2.decoder.decode(zq))
+    assert same(ad1.decoder.decode(zq), ad2.decoder.decode(zq))
 
 
 def test_workgroup_share_changes_only_the_summation_order(gpu, ckpt_root):
