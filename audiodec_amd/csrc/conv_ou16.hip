@@ -100,9 +100,13 @@ template <int N> __device__ __forceinline__ void ou8_wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is six bits");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else static_assert(N == 0, "add the count");
 }
@@ -130,20 +134,25 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
     unsigned char* w2l = lds + W1B;
     unsigned char* ring = w2l + W2B + wave * OU8_RING;     // this wave's ring; later its rows of act(c): row r at r * OU8_RSC
     unsigned char* halo = w2l + W2B + 8 * OU8_RING;        // [8][OU8_RSC]: act(c) of the step in front of wave w's first one (w = 0: the history row)
-    unsigned char* stage = halo + 8 * OU8_RSC + wave * 1024;    // [8][1 KiB]: every wave fetches {c[-1] | bias 2 | bias 1} (equal DMA counts); wave 0's copy is used
-    unsigned char* stage0 = halo + 8 * OU8_RSC;
-    float* clast = reinterpret_cast<float*>(stage0 + 8 * 1024);
+    unsigned char* stage0 = halo + 8 * OU8_RSC;            // 1 KiB: {c[-1] | bias 2 | bias 1}, fetched by wave 0
+    float* clast = reinterpret_cast<float*>(stage0 + 1024);
     typedef unsigned char __attribute__((address_space(3)))* lds_u8_t;
     const unsigned lds0 = (unsigned)(size_t)(lds_u8_t)lds;
     const unsigned lane16 = (unsigned)lane * 16u;
+    const bool act = __builtin_amdgcn_readfirstlane(wave * 16 < T ? 1 : 0) != 0;     // a wave whose 16 steps all lie past the end only helps with the weights
 
-    // ---- every byte by LDS-DMA, oldest first: {c[-1], biases} (1), W1 (6 per wave), column blocks 0-2 (2 each), W2 (2 MT2 per wave) ----
-    {
+    // ---- every byte by LDS-DMA, oldest first: {c[-1], biases} (wave 0 only), W1 (6 per wave), column blocks 0-2 (2 each); blocks 3-5 follow from
+    // inside GEMM 1 as ring slots fall free, W2 (2 MT2 per wave) behind block 5's request -- it is needed last.  The hand-counted waits say how
+    // many of THIS wave's instructions may still be in flight (wave 0's extra one is its oldest: the same counts hold for it).
+    // (W1 cut into the 8 KiB each column block multiplies and requested block by block with a barrier per block, so that GEMM 1 could start on
+    // 24 KiB: measured slower, 9.2 against 8.7-9.0 us -- the issue of DMA instructions itself proceeds at the CU's fill rate, ~24 ns per KiB
+    // with 256 workgroups at it, so what is asked for first is there first either way and the extra barriers only add waits.)
+    if (wave == 0) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a1.wfrag) + lane16;
         if (lane < 16) src = reinterpret_cast<const unsigned char*>(a2.in + ((size_t)b * a2.in_rows + a2.in_row0) * a2.in_ch + a2.in_choff) + lane16;
         else if (lane < 16 + 8 * MT2) { if (a2.bias) src = reinterpret_cast<const unsigned char*>(a2.bias) + (lane - 16) * 16; }
         else if (lane >= 40 && lane < 56) { if (a1.bias) src = reinterpret_cast<const unsigned char*>(a1.bias) + (lane - 40) * 16; }
-        OU_DMA16(src, lds0 + (unsigned)(stage - lds));
+        OU_DMA16(src, lds0 + (unsigned)(stage0 - lds));
     }
     {
         const unsigned char* g1 = reinterpret_cast<const unsigned char*>(a1.wfrag) + (size_t)tid * 16;
@@ -167,39 +176,30 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
 #pragma unroll
         for (int j = 0; j < 2; ++j) OU_DMA16(xsrc[j] + 128 * cb, dst + 1024u * j);
     };
-    issue_block(0); issue_block(1); issue_block(2);
-    {
+    constexpr int W2N = W2B / 8192;                        // W2 instructions per wave: 2 * MT2
+    auto issue_w2 = [&]() __attribute__((always_inline)) {
         const unsigned char* g2 = reinterpret_cast<const unsigned char*>(a2.wfrag) + (size_t)tid * 16;
         const unsigned l2 = lds0 + (unsigned)W1B + (unsigned)wave * 1024u;
 #pragma unroll
-        for (int i = 0; i < W2B / 8192; ++i) OU_DMA16(g2 + 8192 * i, l2 + 8192u * i);
-    }
-    OU_STAMP(1);
-    constexpr int W2N = W2B / 8192;                        // W2 instructions per wave: 2 * MT2
-    ou8_wait_vm<4 + W2N>();                                // {stage, W1, block 0} landed; blocks 1-2 and W2 may stay in flight
-    __syncthreads();
-    OU_STAMP(2);
-    if (tid < OU_CM / 4) {                                 // history row: activation, split, into the halo row of wave 0
-        const float4 hrow = *reinterpret_cast<const float4*>(stage0 + 16 * tid);
-        const float x[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
-        f16x4u hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = ou_act<ACT>(x[e], a2.slope);
-            const _Float16 h = (_Float16)v;
-            hi[e] = h; lo[e] = (_Float16)((v - (float)h) * kOuLoScale);
-        }
-        *reinterpret_cast<f16x4u*>(halo + 8 * tid) = hi;
-        *reinterpret_cast<f16x4u*>(halo + 2 * OU_CM + 8 * tid) = lo;
-    }
+        for (int i = 0; i < W2N; ++i) OU_DMA16(g2 + 8192 * i, l2 + 8192u * i);
+    };
     const float* b2l = reinterpret_cast<const float*>(stage0 + 256);
     const float* b1l = reinterpret_cast<const float*>(stage0 + 640);
     // this lane's A-fragment address inside a packed 32-row m-tile: rows 16 * (m16 & 1) + l15, k-half kg & 1 of 16-k chunk 2 q + (kg >> 1)
     const unsigned a_lane = (unsigned)(l15 + 32 * (kg & 1)) * 16u + (unsigned)(kg >> 1) * 2048u;
-
     float chk = 0.f;                                        // stays 0 while every output is finite
-    // ---- GEMM 1: c[m][t] = sum_k W1[m][k] x[k][t], 64 rows (four 16-row m-tiles) x this wave's 16 steps; one column block = one 32-k step ----
-    {
+
+    if (!act) {
+        OU_STAMP(1);
+        ou8_wait_vm<0>(); __syncthreads();                 // its pieces of W1 have landed
+        OU_STAMP(2);
+        issue_w2();
+        ou8_wait_vm<0>();
+        OU_STAMP(3);
+    } else {
+        // ---- GEMM 1: c[m][t] = sum_k W1[m][k] x[k][t], 64 rows (four 16-row m-tiles) x this wave's 16 steps; one column block = one 32-k step ----
+        issue_block(0); issue_block(1); issue_block(2);
+        OU_STAMP(1);
         f32x4m am[4], ac[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -210,16 +210,35 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
         // as in the four-wave form the compiler's own placement of the fragment reads is the better one)
 #pragma unroll
         for (int cb = 0; cb < OU_NCB; ++cb) {
-            if (cb == 1 || cb == 2) ou8_wait_vm<4 + W2N>();
-            else if (cb == 3) ou8_wait_vm<4>();
-            else if (cb == 4) ou8_wait_vm<2>();
-            else if (cb == 5) ou8_wait_vm<0>();
+            // in flight at most (12 issued up front, + 2 per block requested in the loop, + W2N behind block 5):
+            if (cb == 0) { ou8_wait_vm<4>(); __syncthreads(); }                 // {W1, block 0} landed here -- and, behind the barrier, everybody's W1
+            else if (cb == 1 || cb == 2) ou8_wait_vm<4>();
+            else if (cb == 3) ou8_wait_vm<4 + W2N>();                           // blocks 4, 5 and W2 may stay in flight
+            else if (cb == 4) ou8_wait_vm<2 + W2N>();
+            else ou8_wait_vm<W2N>();
+            if (cb == 0) {
+                OU_STAMP(2);
+                if (tid < OU_CM / 4) {                     // history row: activation, split, into the halo row of wave 0
+                    const float4 hrow = *reinterpret_cast<const float4*>(stage0 + 16 * tid);
+                    const float x[4] = {hrow.x, hrow.y, hrow.z, hrow.w};
+                    f16x4u hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = ou_act<ACT>(x[e], a2.slope);
+                        const _Float16 h = (_Float16)v;
+                        hi[e] = h; lo[e] = (_Float16)((v - (float)h) * kOuLoScale);
+                    }
+                    *reinterpret_cast<f16x4u*>(halo + 8 * tid) = hi;
+                    *reinterpret_cast<f16x4u*>(halo + 2 * OU_CM + 8 * tid) = lo;
+                }
+            }
             const unsigned char* xs = ring + (cb % 3) * OU8_SLOT + l15 * 128;
             const float4 x0 = *reinterpret_cast<const float4*>(xs + 16 * ((unsigned)(2 * kg) ^ swz));
             const float4 x1 = *reinterpret_cast<const float4*>(xs + 16 * ((unsigned)(2 * kg + 1) ^ swz));
             if (cb + 3 < OU_NCB) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads of this slot have returned: it may be overwritten
                 issue_block(cb + 3);
+                if (cb + 3 == OU_NCB - 1) issue_w2();
             }
             const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             f16x8u bh, bl;
@@ -242,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
 #pragma unroll
             for (int m = 0; m < 4; ++m) ac[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[m], bh, ac[m], 0, 0, 0);
         }
+        ou8_wait_vm<0>();                                  // W2
         OU_STAMP(3);
         // c (+ bias): act(c), split, over this wave's ring; the last step's raw row to `clast`; the row the NEXT wave's first step needs as
         // its older tap to that wave's halo row.  Lane (column l15, kg) holds channels 16 m + 4 kg + {0..3}.
@@ -277,57 +297,59 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
     __syncthreads();                                       // (W2 landed with the last column block: vmcnt(0) above)
     OU_STAMP(4);
 
-    // ---- GEMM 2: the polyphase transposed conv; k = (tap j, channel): 32-k step q = tap q / 2, channels 32 (q & 1) ..; tap 0 = c[t-1], tap 1 = c[t] ----
-    int orow0 = a2.out_cursor + t * a2.up;
-    orow0 %= a2.out_rows;
-    const unsigned char* xr0 = (l15 == 0 ? halo + wave * OU8_RSC : ring + (l15 - 1) * OU8_RSC) + 16 * kg;
-    const unsigned char* xr1 = ring + l15 * OU8_RSC + 16 * kg;
-    f16x8u bh[4], bl[4];
+    if (act) {
+        // ---- GEMM 2: the polyphase transposed conv; k = (tap j, channel): 32-k step q = tap q / 2, channels 32 (q & 1) ..; tap 0 = c[t-1], tap 1 = c[t] ----
+        int orow0 = a2.out_cursor + t * a2.up;
+        orow0 %= a2.out_rows;
+        const unsigned char* xr0 = (l15 == 0 ? halo + wave * OU8_RSC : ring + (l15 - 1) * OU8_RSC) + 16 * kg;
+        const unsigned char* xr1 = ring + l15 * OU8_RSC + 16 * kg;
+        f16x8u bh[4], bl[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const unsigned char* p = (q >> 1 ? xr1 : xr0) + 64 * (q & 1);
-        bh[q] = *reinterpret_cast<const f16x8u*>(p);
-        bl[q] = *reinterpret_cast<const f16x8u*>(p + 2 * OU_CM);
-    }
-    const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(a2.out, 0, u.out_bytes, 0x00020000);
-    const unsigned out_base = ((unsigned)b * (unsigned)a2.out_rows * (unsigned)a2.out_ch + (unsigned)a2.out_choff) * 4u;
-    const unsigned row_bytes = (unsigned)a2.out_ch * 4u;
-    const bool has_b2 = a2.bias != nullptr;
-    const unsigned oob_mask = valid ? 0u : 0x80000000u;    // columns past the end: the store goes out of bounds (dropped), no branch
-    f32x4m am2[M2], ac2[M2];
-#pragma unroll
-    for (int m = 0; m < M2; ++m)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { am2[m][e] = 0.f; ac2[m][e] = 0.f; }
-#pragma unroll
-    for (int m = 0; m <= M2; ++m) {
-        if (m < M2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned char* wp = w2l + (size_t)((m >> 1) * OU_KS2 + 2 * q) * 2048 + (m & 1) * 256 + a_lane;
-                const f16x8u Ah = *reinterpret_cast<const f16x8u*>(wp);
-                const f16x8u Al = *reinterpret_cast<const f16x8u*>(wp + 1024);
-                am2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, bh[q], am2[m], 0, 0, 0);
-                ac2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, bl[q], ac2[m], 0, 0, 0);
-                ac2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, bh[q], ac2[m], 0, 0, 0);
-            }
+        for (int q = 0; q < 4; ++q) {
+            const unsigned char* p = (q >> 1 ? xr1 : xr0) + 64 * (q & 1);
+            bh[q] = *reinterpret_cast<const f16x8u*>(p);
+            bl[q] = *reinterpret_cast<const f16x8u*>(p + 2 * OU_CM);
         }
-        if (m > 0) {
-            const int m1 = m - 1;                          // finish of the previous m-tile: GEMM rows 16 m1 + 4 kg + {0..3}
-            const int ml = 16 * m1 + 4 * kg;
-            float4 v = make_float4(fmaf(ac2[m1][0], kOuLoInv, am2[m1][0]), fmaf(ac2[m1][1], kOuLoInv, am2[m1][1]),
-                                   fmaf(ac2[m1][2], kOuLoInv, am2[m1][2]), fmaf(ac2[m1][3], kOuLoInv, am2[m1][3]));
-            chk = fmaf(v.x, 0.f, chk); chk = fmaf(v.y, 0.f, chk); chk = fmaf(v.z, 0.f, chk); chk = fmaf(v.w, 0.f, chk);
-            float4 bb = *reinterpret_cast<const float4*>(b2l + ml);
-            bb.x = has_b2 ? bb.x : 0.f; bb.y = has_b2 ? bb.y : 0.f; bb.z = has_b2 ? bb.z : 0.f; bb.w = has_b2 ? bb.w : 0.f;
-            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-            const int ph = (int)(((float)ml + 0.5f) * u.inv_cout_real);        // ml / cout_real, exact for these sizes
-            int r2 = orow0 + ph;
-            if (r2 >= a2.out_rows) r2 -= a2.out_rows;
-            const unsigned off = (out_base + (unsigned)r2 * row_bytes + (unsigned)(ml - ph * a2.cout_real) * 4u) | oob_mask;
-            u32x4o pv;
-            pv.x = __float_as_uint(v.x); pv.y = __float_as_uint(v.y); pv.z = __float_as_uint(v.z); pv.w = __float_as_uint(v.w);
-            __builtin_amdgcn_raw_buffer_store_b128(pv, rsrc_out, off, 0, 0);
+        const __amdgpu_buffer_rsrc_t rsrc_out = __builtin_amdgcn_make_buffer_rsrc(a2.out, 0, u.out_bytes, 0x00020000);
+        const unsigned out_base = ((unsigned)b * (unsigned)a2.out_rows * (unsigned)a2.out_ch + (unsigned)a2.out_choff) * 4u;
+        const unsigned row_bytes = (unsigned)a2.out_ch * 4u;
+        const bool has_b2 = a2.bias != nullptr;
+        const unsigned oob_mask = valid ? 0u : 0x80000000u;    // columns past the end: the store goes out of bounds (dropped), no branch
+        f32x4m am2[M2], ac2[M2];
+#pragma unroll
+        for (int m = 0; m < M2; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { am2[m][e] = 0.f; ac2[m][e] = 0.f; }
+#pragma unroll
+        for (int m = 0; m <= M2; ++m) {
+            if (m < M2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned char* wp = w2l + (size_t)((m >> 1) * OU_KS2 + 2 * q) * 2048 + (m & 1) * 256 + a_lane;
+                    const f16x8u Ah = *reinterpret_cast<const f16x8u*>(wp);
+                    const f16x8u Al = *reinterpret_cast<const f16x8u*>(wp + 1024);
+                    am2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, bh[q], am2[m], 0, 0, 0);
+                    ac2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, bl[q], ac2[m], 0, 0, 0);
+                    ac2[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, bh[q], ac2[m], 0, 0, 0);
+                }
+            }
+            if (m > 0) {
+                const int m1 = m - 1;                          // finish of the previous m-tile: GEMM rows 16 m1 + 4 kg + {0..3}
+                const int ml = 16 * m1 + 4 * kg;
+                float4 v = make_float4(fmaf(ac2[m1][0], kOuLoInv, am2[m1][0]), fmaf(ac2[m1][1], kOuLoInv, am2[m1][1]),
+                                       fmaf(ac2[m1][2], kOuLoInv, am2[m1][2]), fmaf(ac2[m1][3], kOuLoInv, am2[m1][3]));
+                chk = fmaf(v.x, 0.f, chk); chk = fmaf(v.y, 0.f, chk); chk = fmaf(v.z, 0.f, chk); chk = fmaf(v.w, 0.f, chk);
+                float4 bb = *reinterpret_cast<const float4*>(b2l + ml);
+                bb.x = has_b2 ? bb.x : 0.f; bb.y = has_b2 ? bb.y : 0.f; bb.z = has_b2 ? bb.z : 0.f; bb.w = has_b2 ? bb.w : 0.f;
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                const int ph = (int)(((float)ml + 0.5f) * u.inv_cout_real);        // ml / cout_real, exact for these sizes
+                int r2 = orow0 + ph;
+                if (r2 >= a2.out_rows) r2 -= a2.out_rows;
+                const unsigned off = (out_base + (unsigned)r2 * row_bytes + (unsigned)(ml - ph * a2.cout_real) * 4u) | oob_mask;
+                u32x4o pv;
+                pv.x = __float_as_uint(v.x); pv.y = __float_as_uint(v.y); pv.z = __float_as_uint(v.z); pv.w = __float_as_uint(v.w);
+                __builtin_amdgcn_raw_buffer_store_b128(pv, rsrc_out, off, 0, 0);
+            }
         }
     }
     if (tid < OU_CM / 4) {                                  // the next call's history row of c, behind everything else
@@ -366,7 +388,7 @@ int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s) {
     u.err = conv_err_word(a1);
     u.out_bytes = (unsigned)((unsigned long long)a2.batch * a2.out_rows * a2.out_ch * 4ull);        // < 2^31: conv_ou16_fusable
     const int mt2 = a2.cout_g / 32;
-    const size_t lds = (size_t)2 * u.ks1p * 2048 + (size_t)mt2 * OU_KS2 * 2048 + (size_t)8 * OU8_RING + (size_t)8 * OU8_RSC + 8 * 1024 + OU_CM * sizeof(float);
+    const size_t lds = (size_t)2 * u.ks1p * 2048 + (size_t)mt2 * OU_KS2 * 2048 + (size_t)8 * OU8_RING + (size_t)8 * OU8_RSC + 1024 + OU_CM * sizeof(float);
     // a function attribute belongs to ONE instantiation (and one device): the flags are keyed by the (ACT, MT2) pair -- every
     // instantiation decays to the same pointer type, so a flag inside a generic lambda over that pointer would be shared by all of them
     auto go = [&](auto act, auto mt) -> int {

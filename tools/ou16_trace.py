@@ -67,7 +67,7 @@ def main():
     t0 = a[:, 0].min()
     print(f"{B} workgroups (one per stream); times in us (10 ns ticks); launch span (first entry -> last exit) {(a[:, 5].max() - t0) / 100.0:.2f}")
     print(f"workgroup entry spread {(a[:, 0].max() - t0) / 100.0:.2f}; median workgroup duration {np.median(a[:, 5] - a[:, 0]) / 100.0:.2f}")
-    names = ["issue: 19 LDS-DMA instructions per wave (biases + c[-1], W1, column blocks 0-2 of the wave's tile, W2)", "wait: {biases, W1, block 0} landed, first barrier",
+    names = ["issue: 12 LDS-DMA instructions per wave (W1, column blocks 0-2 of the tile; wave 0 also biases + c[-1])", "wait: {biases, W1, block 0} landed, barrier",
              "GEMM 1 (72 MFMAs of 16 x 16 x 32 per wave; blocks 1-5 stream in beneath it; f16 split of the fragments)", "epilogue 1: act(c), split -> LDS, second barrier",
              "GEMM 2 (72 MFMAs per wave) + 6 x 16 B stores per lane issued"]
     for i, n in enumerate(names):
