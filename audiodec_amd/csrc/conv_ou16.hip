@@ -146,7 +146,9 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
     // many of THIS wave's instructions may still be in flight (wave 0's extra one is its oldest: the same counts hold for it).
     // (W1 cut into the 8 KiB each column block multiplies and requested block by block with a barrier per block, so that GEMM 1 could start on
     // 24 KiB: measured slower, 9.2 against 8.7-9.0 us -- the issue of DMA instructions itself proceeds at the CU's fill rate, ~24 ns per KiB
-    // with 256 workgroups at it, so what is asked for first is there first either way and the extra barriers only add waits.)
+    // with 256 workgroups at it, so what is asked for first is there first either way and the extra barriers only add waits.  Also measured, no
+    // gain: block 0 -- the cold bytes; the weights sit in the L2s -- requested in front of W1 (9.0); W1 in two halves of K, the second behind
+    // blocks 0-2, one more barrier (9.2).  experiments/sessions/r6_s17.sh, runs 18-21.)
     if (wave == 0) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(a1.wfrag) + lane16;
         if (lane < 16) src = reinterpret_cast<const unsigned char*>(a2.in + ((size_t)b * a2.in_rows + a2.in_row0) * a2.in_ch + a2.in_choff) + lane16;
