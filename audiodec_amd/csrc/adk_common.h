@@ -91,6 +91,9 @@ const char* conv_rb16_name(const ConvArgs* c, int n);
 // conv_out (1x1, 192 -> 64) + activation + the last up-sampler's transposed conv as one streaming launch (conv_ou16.hip)
 bool conv_ou16_fusable(const ConvArgs& a1, const ConvArgs& a2);
 int launch_conv_ou16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s);     // ADK_ERR_STATE: not fusable for this call
+// the last conv_out (1x1, 96 -> 32) + activation + the output conv (K7, 32 -> 1) + its output activation as one streaming launch (conv_oc16.hip)
+bool conv_oc16_fusable(const ConvArgs& a1, const ConvArgs& a2);
+int launch_conv_oc16(const ConvArgs& a1, const ConvArgs& a2, hipStream_t s);     // ADK_ERR_STATE: not fusable for this call
 bool conv_up16_supported(const ConvArgs& a);        // streaming kernel of the last up-sampling stage (64 -> s*Cout <= 96 rows, 2 taps)
 int launch_conv_up16(const ConvArgs& a, hipStream_t s);
 int launch_conv_sk16(const ConvArgs& a, hipStream_t s, Workspace& ws);   // split-f16 stream-K (same shapes as launch_conv_mfma)

@@ -452,17 +452,23 @@ static int op_conv_args(adk_program* p, int i, int frames, void* const* ext, Con
 }
 
 // Can ops i, i+1 run as one launch for a `frames`-hop step?  0: no; 1: a residual unit (conv -> 1x1 + residual: conv_rl16 FUSE);
-// 2: the 1x1 conv_out of a vocoder stage + the next stage's activation and transposed conv (conv_ou16)
+// 2: the 1x1 conv_out of a vocoder stage + the next stage's activation and transposed conv (conv_ou16);
+// 3: the last 1x1 conv_out + activation + the output conv and its activation (conv_oc16)
 static int g_use_ou = -1;       // ADK_CONV_OU16=0: conv_out and the up-sampler stay two launches (A/B)
+static int g_use_oc = -1;       // ADK_CONV_OC16=0: the last conv_out and the output conv stay two launches (A/B)
 static int op_pair_kind(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a1, ConvArgs& a2) {
     read_env();
     if (g_use_ou < 0) { const char* e = getenv("ADK_CONV_OU16"); g_use_ou = e ? atoi(e) : 1; }
+    if (g_use_oc < 0) { const char* e = getenv("ADK_CONV_OC16"); g_use_oc = e ? atoi(e) : 1; }
     if (i + 1 >= (int)p->ops.size()) return 0;
     const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
-    if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16 || o2.impl != ADK_IMPL_SPLIT16) return 0;
+    if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16) return 0;
     if (o2.in_ring != o1.out_ring || p->rings[o1.out_ring].external >= 0) return 0;
     if (o1.out_shadow > 0 || o2.out_shadow > 0) return 0;        // (only the stream-K kernel's epilogue writes shadow rings)
     if (op_conv_args(p, i, frames, ext, a1) != ADK_OK || op_conv_args(p, i + 1, frames, ext, a2) != ADK_OK) return 0;
+    if (o2.impl == ADK_IMPL_AUTO && o2.conv.groups * o2.conv.cout_g == 1)      // (a one-channel conv has no matrix-core form: exact f32 in either arithmetic)
+        return g_use_oc && conv_oc16_fusable(a1, a2) ? 3 : 0;
+    if (o2.impl != ADK_IMPL_SPLIT16) return 0;
     if (g_use_rl && conv_rl16_fusable(a1, a2)) return 1;
     if (g_use_ou && g_use_up && conv_ou16_fusable(a1, a2)) return 2;
     return 0;
@@ -510,7 +516,7 @@ static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream
         if (consumed && max_consume >= 2 && o.fuse_next) {
             const int kind = op_pair_kind(p, i, frames, ext, a, a2);
             if (kind) {
-                rc = kind == 1 ? launch_conv_rl16_fused(a, a2, s) : launch_conv_ou16(a, a2, s);
+                rc = kind == 1 ? launch_conv_rl16_fused(a, a2, s) : (kind == 2 ? launch_conv_ou16(a, a2, s) : launch_conv_oc16(a, a2, s));
                 if (rc == ADK_OK) { *consumed = 2; return ADK_OK; }
                 if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (fused): " + g_err; return rc; }
             }
@@ -731,7 +737,7 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
         for (int h = op; h >= 0 && h > op - kMaxChain; --h)
             if (p->ops[h].kind == ADK_OP_CONV && p->ops[h].chain >= 2 && h + p->ops[h].chain > op) { head = h; break; }
         if (head >= 0 && op_chain_fusable(p, head, frames, ext, c, keep)) name = head == op ? conv_rb16_name(c, p->ops[head].chain) : "(fused into the previous op)";
-        else if (o.fuse_next && op_pair_kind(p, op, frames, ext, f1, f2)) name = op_pair_kind(p, op, frames, ext, f1, f2) == 2 ? "conv_ou16<192>" : (f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>");
+        else if (o.fuse_next && op_pair_kind(p, op, frames, ext, f1, f2)) { const int k = op_pair_kind(p, op, frames, ext, f1, f2); name = k == 2 ? "conv_ou16<192>" : (k == 3 ? "conv_oc16<96>" : (f1.cin_g == 32 ? "conv_rl16_unit<32>" : "conv_rl16_unit<64>")); }
         else if (op > 0 && p->ops[op - 1].fuse_next && op_pair_kind(p, op - 1, frames, ext, f1, f2)) name = "(fused into the previous op)";
     }
     snprintf(buf, n, "%s", name.c_str());

@@ -487,7 +487,9 @@ def _build_hifigan(sd, p, offline, split16, part, cuts):
             # the 1x1 conv_out feeds only the next stage's activation + transposed conv: the runner may run the two as one
             # streaming launch (csrc/conv_ou16.hip; the 64-channel tensor between them then never exists in memory)
             nxt_is_up = i + 1 < last and cur_internal and not offline and FUSE_RES_UNITS
-            b.conv(f"blocks.{i}.conv_out", x, cur, fuse_next=nxt_is_up)
+            # ... and the last one only the output conv: csrc/conv_oc16.hip (of the 32-channel tensor only the last 6 steps are stored)
+            nxt_is_out = i + 1 == n_up and last == n_up and not offline and FUSE_RES_UNITS
+            b.conv(f"blocks.{i}.conv_out", x, cur, fuse_next=nxt_is_up or nxt_is_out)
         else:
             # MultiReceptiveField.inference (multi_fusion.py:73-79): mean of the residual blocks, all fed by x0
             outs = []
