@@ -70,6 +70,8 @@ struct RingMeanArgs {
 int launch_ring_mean(const RingMeanArgs& m, hipStream_t s);
 int launch_hist_replicate(float* ring, int rows, int channels, int cursor, int hist, int batch, hipStream_t s);
 int launch_conv_direct(const ConvArgs& a, hipStream_t s);
+bool conv_cin1_write_ok(const ConvArgs& a);           // the Cin = 1 K7 conv + the ring write in front of it as one launch (conv_direct.hip)
+int launch_conv_cin1_write(const ConvArgs& a, const float* src, hipStream_t s);      // ADK_ERR_STATE: not for this call
 // scratch of the stream-K conv: partial accumulators of cut tiles + publish flags (zeroed once at
 // allocation; flags carry a per-launch epoch, so they are never reset)
 struct Workspace { float* ptr = nullptr; size_t bytes = 0; size_t flags_offset = 0; unsigned epoch = 0;

@@ -77,6 +77,49 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(ConvArgs a) {
     }
 }
 
+// The same conv when the ring write of the caller's samples stands right in front of it (the first two ops of the encoder program:
+// audio -> ring, ring -> 32 channels): ONE launch.  New samples are read from the caller's buffer src[b][t] (the ring would hand back the very
+// same values), the TAPS - 1 samples in front of the step from the ring -- what earlier steps left there --, and the lanes of channel piece 0
+// copy the step's samples into the ring for the steps to come (and for a replay of this one: ADK_STEP_REPLAY runs the plain kernel on the
+// ring).  Same fma order as conv_cin1_kernel: bit-identical.
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_cin1w_kernel(ConvArgs a, const float* __restrict__ src, float* __restrict__ ring) {
+    const int M = a.cout_g;
+    const int q = M / 4;
+    const int c4 = threadIdx.x % q;
+    float w[4][TAPS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) w[k][j] = a.w[(size_t)(4 * c4 + k) * TAPS + j];
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + 4 * c4);
+    const int per_block = 256 / q;
+    for (long long n0 = (long long)blockIdx.x * per_block; n0 < a.n_total; n0 += (long long)gridDim.x * per_block) {
+        const int n = (int)n0 + threadIdx.x / q;
+        if (n >= a.n_total) continue;
+        const int b = n / a.t_out, t = n - b * a.t_out;
+        const float* xs = src + (size_t)b * a.t_out;
+        float* xr = ring + (size_t)b * a.in_rows * a.in_ch + a.in_choff;
+        float4 acc = bias;
+        int row = a.in_row0 + t;                             // ring row of sample t - (TAPS - 1)
+        if (row >= a.in_rows) row -= a.in_rows;
+#pragma unroll
+        for (int j = 0; j < TAPS; ++j) {
+            const int sidx = t + j - (TAPS - 1);
+            const float x = act_apply(sidx >= 0 ? xs[sidx] : xr[(size_t)row * a.in_ch], a.act_in, a.slope);
+            acc.x = fmaf(w[0][j], x, acc.x); acc.y = fmaf(w[1][j], x, acc.y);
+            acc.z = fmaf(w[2][j], x, acc.z); acc.w = fmaf(w[3][j], x, acc.w);
+            if (j == TAPS - 1 && c4 == 0) xr[(size_t)row * a.in_ch] = xs[t];      // (row is the ring row of sample t here)
+            row += 1;
+            if (row >= a.in_rows) row -= a.in_rows;
+        }
+        int orow = a.out_cursor + t;
+        if (orow >= a.out_rows) orow -= a.out_rows;
+        *reinterpret_cast<float4*>(a.out + ((size_t)b * a.out_rows + orow) * a.out_ch + a.out_choff + 4 * c4) = acc;
+    }
+}
+
 // Cout_total == 1 (output conv 32 -> 1, K7 + tanh): one workgroup = 256 consecutive steps of one stream.
 // The (256 + hist) input rows are staged once into LDS (coalesced float4 loads, activation applied once,
 // row stride Cin+1 so that lanes walking consecutive rows hit distinct banks), then each lane forms its
@@ -144,6 +187,25 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t s) {
         if (blocks > 65536 * 4) blocks = 65536 * 4;
         hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     }
+    ADK_HIP_CHECK(hipGetLastError());
+    return ADK_OK;
+}
+
+// the Cin = 1, K7 conv with the ring write of its input in the same launch (conv_cin1w_kernel): a's input view is the ring AFTER the write
+// would have happened (in_row0 = write cursor - 6); src = the caller's rows (batch x t_out samples, one channel)
+bool conv_cin1_write_ok(const ConvArgs& a) {
+    const int M = a.groups * a.cout_g;
+    return a.cin_g == 1 && a.groups == 1 && a.up == 1 && a.taps == 7 && a.stride == 1 && a.dilation == 1 && a.w && M % 4 == 0 && 256 % (M / 4) == 0 &&
+           a.out_ch % 4 == 0 && a.out_choff % 4 == 0 && !a.res && a.act_out == ADK_ACT_NONE && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+           (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0) && a.in_rows >= a.t_out + 6;
+}
+int launch_conv_cin1_write(const ConvArgs& a, const float* src, hipStream_t s) {
+    if (!conv_cin1_write_ok(a) || !src) return ADK_ERR_STATE;
+    if (a.n_total == 0) return ADK_OK;
+    const int per_block = 256 / (a.cout_g / 4);
+    long long blocks = ((long long)a.n_total + per_block - 1) / per_block;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_cin1w_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, s, a, src, const_cast<float*>(a.in));
     ADK_HIP_CHECK(hipGetLastError());
     return ADK_OK;
 }

@@ -496,6 +496,18 @@ static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext
     return conv_rb16_fusable(c, n);
 }
 
+// Op i writes the caller's rows into a one-channel ring and op i + 1 is the Cin = 1 conv that reads it: one launch (conv_cin1w_kernel)?
+static int g_use_cw = -1;       // ADK_CONV_CIN1W=0: the ring write stays a launch of its own (A/B)
+static bool op_write_conv_fusable(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a) {
+    if (g_use_cw < 0) { const char* e = getenv("ADK_CONV_CIN1W"); g_use_cw = e ? atoi(e) : 1; }
+    if (!g_use_cw || i + 1 >= (int)p->ops.size()) return false;
+    const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
+    if (o1.kind != ADK_OP_RING_WRITE || o2.kind != ADK_OP_CONV || o1.mean_off >= 0 || o1.scale_off >= 0 || o2.in_ring != o1.out_ring) return false;
+    if (o2.impl != ADK_IMPL_AUTO || p->rings[o1.out_ring].channels != 1 || p->rings[o1.out_ring].external >= 0 || o2.in_shadow > 0 || o2.out_shadow > 0) return false;
+    if (op_conv_args(p, i + 1, frames, ext, a) != ADK_OK) return false;
+    return a.t_out == frames * p->rings[o1.out_ring].rate && conv_cin1_write_ok(a);
+}
+
 // one op of the launch sequence on stream s; *consumed = how many ops of the sequence this launch covered (a residual unit or a
 // whole residual chain run as one kernel), at most max_consume
 static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream_t s, int max_consume = 1, int* consumed = nullptr) {
@@ -540,6 +552,12 @@ static int run_op(adk_program* p, int i, int frames, void* const* ext, hipStream
             rc = launch_hist_replicate(v.base, v.rows, v.channels, v.cursor, p->rings[o.in_ring].hist, p->batch, s);
         }
     } else {
+        ConvArgs a;
+        if (consumed && max_consume >= 2 && ext[o.ext_src] && op_write_conv_fusable(p, i, frames, ext, a)) {
+            rc = launch_conv_cin1_write(a, static_cast<const float*>(ext[o.ext_src]), s);
+            if (rc == ADK_OK) { *consumed = 2; return ADK_OK; }
+            if (rc != ADK_ERR_STATE) { g_err = "op " + std::to_string(i) + " (ring write + conv): " + g_err; return rc; }
+        }
         adk_ring_view out = view_of(p, o.out_ring, frames, ext, 0);
         const float* mean = o.mean_off >= 0 ? p->weights + o.mean_off : nullptr;
         const float* scale = o.scale_off >= 0 ? p->weights + o.scale_off : nullptr;
@@ -713,7 +731,13 @@ extern "C" int adk_program_describe_op(adk_program* p, int32_t op, int32_t frame
     if (!p || !buf || n <= 0 || op < 0 || op >= (int)p->ops.size()) return fail(ADK_ERR_ARG, "program_describe_op: bad arguments");
     const adk_op_desc& o = p->ops[op];
     std::string name = o.kind == ADK_OP_MEAN ? "ring_mean" : (o.kind == ADK_OP_HIST_REPLICATE ? "hist_replicate" : "ring_write");
-    if (o.kind == ADK_OP_CONV) {
+    alignas(16) static float aligned_dummy0[4];
+    void* ext0[8];
+    for (auto& e : ext0) e = aligned_dummy0;
+    ConvArgs wa;
+    if (o.kind == ADK_OP_RING_WRITE && op_write_conv_fusable(p, op, frames, ext0, wa)) name = "ring_write+conv_cin1";
+    else if (o.kind == ADK_OP_CONV && op > 0 && op_write_conv_fusable(p, op - 1, frames, ext0, wa)) name = "(in the launch of the ring write)";
+    else if (o.kind == ADK_OP_CONV) {
         adk_conv_desc d = o.conv;
         d.w = o.w_off >= 0 ? p->weights + o.w_off : nullptr;
         d.w_frag = o.wf_off >= 0 ? p->weights + o.wf_off : nullptr;

@@ -269,6 +269,7 @@ def rocprof_duration(dom, stats_file=None, config=None):
 
 
 FUSED = "(fused into the previous op)"
+IN_RING_WRITE = "(in the launch of the ring write)"      # the Cin = 1 conv behind a ring write: one launch (conv_cin1w_kernel)
 
 
 def launches_of(rows, streams, fps=1):
@@ -282,13 +283,15 @@ def launches_of(rows, streams, fps=1):
     avoid moving."""
     out = []
     for r in rows:
-        if r["kernel"] == FUSED and out and out[-1]["prog"] == r["prog"]:
+        if r["kernel"] in (FUSED, IN_RING_WRITE) and out and out[-1]["prog"] == r["prog"]:
             L = out[-1]
             L["ms_events_only"] += r["ms"]; L["flops"] += r["flops"]; L["ops"].append(r)
             continue
         out.append(dict(prog=r["prog"], name=r["name"], kernel=r["kernel"], ms=r["ms"], ms_events_only=0.0, flops=r["flops"], bytes=r["bytes"], ops=[r], op=r["op"]))
     for L in out:
-        if len(L["ops"]) > 1:
+        if len(L["ops"]) > 1 and L["ops"][0]["op"].kind != 0:
+            L["bytes"] = sum(q["bytes"] for q in L["ops"][1:])            # ring write + conv: the conv's bytes (the ring rows are written once either way)
+        elif len(L["ops"]) > 1:
             ops = [q["op"] for q in L["ops"]]
             c0 = ops[0].conv
             t = ops[0].rate_out * fps
@@ -310,7 +313,7 @@ def mean_launch_bytes(launches, dom):
 def event_record_ms(rows):
     """What ONE event record costs on the launch stream: median "duration" of the ops that ran inside another op's launch (two event
     records with no kernel in between).  0 when the step has no such op."""
-    gaps = [r["ms"] for r in rows if r["kernel"] == FUSED]
+    gaps = [r["ms"] for r in rows if r["kernel"] in (FUSED, IN_RING_WRITE)]
     return float(np.median(gaps)) if gaps else 0.0
 
 
