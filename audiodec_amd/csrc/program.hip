@@ -77,6 +77,9 @@ static int g_use_chain = -1;    // ADK_CHAIN=0: residual chains run op by op (A/
 static int g_chain_max_c = -1;  // adk_set_option("chain_max_channels") / ADK_CHAIN_MAXC
 static int g_chain_min_c = -1;  // adk_set_option("chain_min_channels") / ADK_CHAIN_MINC
 static int g_chain_min_blocks = -1;   // adk_set_option("chain_min_blocks") / ADK_CHAIN_MIN_BLOCKS: fewer (stream, group) workgroups -> per-op launches
+static int g_use_ou = -1;       // adk_set_option("conv_ou16") / ADK_CONV_OU16=0: conv_out and the last up-sampler stay two launches (A/B, tests)
+static int g_use_oc = -1;       // adk_set_option("conv_oc16") / ADK_CONV_OC16=0: the last conv_out and the output conv stay two launches
+static int g_use_cw = -1;       // adk_set_option("conv_cin1w") / ADK_CONV_CIN1W=0: the encoder's ring write stays a launch of its own
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
@@ -90,6 +93,9 @@ static void read_env() {
     // measured crossover (tools/chain_crossover.py, profiles/r3_chain_crossover.log): below ~160 (stream, group) pairs the per-op launches,
     // which spread one stream's time tiles over many CUs, are faster than one workgroup per pair walking the whole chain
     if (g_chain_min_blocks < 0) { const char* e = getenv("ADK_CHAIN_MIN_BLOCKS"); g_chain_min_blocks = e ? atoi(e) : 0; }
+    if (g_use_ou < 0) { const char* e = getenv("ADK_CONV_OU16"); g_use_ou = e ? atoi(e) : 1; }
+    if (g_use_oc < 0) { const char* e = getenv("ADK_CONV_OC16"); g_use_oc = e ? atoi(e) : 1; }
+    if (g_use_cw < 0) { const char* e = getenv("ADK_CONV_CIN1W"); g_use_cw = e ? atoi(e) : 1; }
 }
 
 static int run_conv(const ConvArgs& a, int impl, hipStream_t s, Workspace& ws) {
@@ -161,6 +167,9 @@ extern "C" int adk_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "chain_max_channels")) { g_chain_max_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_channels")) { g_chain_min_c = value < 0 ? 0 : value; return ADK_OK; }
     if (!strcmp(name, "chain_min_blocks")) { g_chain_min_blocks = value < 0 ? 0 : value; return ADK_OK; }
+    if (!strcmp(name, "conv_ou16")) { g_use_ou = value != 0; return ADK_OK; }
+    if (!strcmp(name, "conv_oc16")) { g_use_oc = value != 0; return ADK_OK; }
+    if (!strcmp(name, "conv_cin1w")) { g_use_cw = value != 0; return ADK_OK; }
     if (conv_set_option(name, value) == 0) return ADK_OK;
     {
         const int r = rvq_set_option(name, value);
@@ -454,12 +463,8 @@ static int op_conv_args(adk_program* p, int i, int frames, void* const* ext, Con
 // Can ops i, i+1 run as one launch for a `frames`-hop step?  0: no; 1: a residual unit (conv -> 1x1 + residual: conv_rl16 FUSE);
 // 2: the 1x1 conv_out of a vocoder stage + the next stage's activation and transposed conv (conv_ou16);
 // 3: the last 1x1 conv_out + activation + the output conv and its activation (conv_oc16)
-static int g_use_ou = -1;       // ADK_CONV_OU16=0: conv_out and the up-sampler stay two launches (A/B)
-static int g_use_oc = -1;       // ADK_CONV_OC16=0: the last conv_out and the output conv stay two launches (A/B)
 static int op_pair_kind(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a1, ConvArgs& a2) {
     read_env();
-    if (g_use_ou < 0) { const char* e = getenv("ADK_CONV_OU16"); g_use_ou = e ? atoi(e) : 1; }
-    if (g_use_oc < 0) { const char* e = getenv("ADK_CONV_OC16"); g_use_oc = e ? atoi(e) : 1; }
     if (i + 1 >= (int)p->ops.size()) return 0;
     const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
     if (o1.kind != ADK_OP_CONV || o2.kind != ADK_OP_CONV || !o1.fuse_next || o1.impl != ADK_IMPL_SPLIT16) return 0;
@@ -497,9 +502,8 @@ static bool op_chain_fusable(adk_program* p, int i, int frames, void* const* ext
 }
 
 // Op i writes the caller's rows into a one-channel ring and op i + 1 is the Cin = 1 conv that reads it: one launch (conv_cin1w_kernel)?
-static int g_use_cw = -1;       // ADK_CONV_CIN1W=0: the ring write stays a launch of its own (A/B)
 static bool op_write_conv_fusable(adk_program* p, int i, int frames, void* const* ext, ConvArgs& a) {
-    if (g_use_cw < 0) { const char* e = getenv("ADK_CONV_CIN1W"); g_use_cw = e ? atoi(e) : 1; }
+    read_env();
     if (!g_use_cw || i + 1 >= (int)p->ops.size()) return false;
     const adk_op_desc &o1 = p->ops[i], &o2 = p->ops[i + 1];
     if (o1.kind != ADK_OP_RING_WRITE || o2.kind != ADK_OP_CONV || o1.mean_off >= 0 || o1.scale_off >= 0 || o2.in_ring != o1.out_ring) return false;

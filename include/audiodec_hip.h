@@ -85,6 +85,10 @@ int adk_set_conv_cfg(int32_t cfg);
  *   "gv16_max_columns"    convs of at most this many columns (streams x steps per call) run as conv_gv16 (csrc/conv_mfma.hip: one wave per
  *                         32-row x 32-column output tile and K slice, no LDS) instead of the stream-K kernel; default 32, 0 = never
  *                         (also env ADK_GV16_MAXN).  Results of the two kernels agree to f32 round-off, not bit for bit.
+ *   "conv_ou16", "conv_oc16", "conv_cin1w"   0: the op pairs these launches cover run as two launches again (defaults 1; also env ADK_CONV_OU16,
+ *                         ADK_CONV_OC16, ADK_CONV_CIN1W): conv_out + the last up-sampler (csrc/conv_ou16.hip: f32 round-off against the two-launch
+ *                         form), the last conv_out + the output conv (csrc/conv_oc16.hip), the encoder's ring write + its Cin = 1 conv
+ *                         (csrc/conv_direct.hip: bit-identical).  A/B measurements and the tests that compare the two forms.
  * ADK_ERR_ARG for an unknown name. */
 int adk_set_option(const char* name, int32_t value);
 /* Introspection of the stream-K launch schedule (pure host logic, no device needed; used by the CPU tests): a matrix-core conv
