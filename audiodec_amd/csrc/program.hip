@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <atomic>
 
 namespace adk {
 
@@ -71,15 +72,16 @@ static int ensure_workspace(Workspace& w) {
     return ADK_OK;
 }
 
-static int g_use_rl = -1;       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
-static int g_use_up = -1;       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
-static int g_use_chain = -1;    // ADK_CHAIN=0: residual chains run op by op (A/B against the per-op kernels)
-static int g_chain_max_c = -1;  // adk_set_option("chain_max_channels") / ADK_CHAIN_MAXC
-static int g_chain_min_c = -1;  // adk_set_option("chain_min_channels") / ADK_CHAIN_MINC
-static int g_chain_min_blocks = -1;   // adk_set_option("chain_min_blocks") / ADK_CHAIN_MIN_BLOCKS: fewer (stream, group) workgroups -> per-op launches
-static int g_use_ou = -1;       // adk_set_option("conv_ou16") / ADK_CONV_OU16=0: conv_out and the last up-sampler stay two launches (A/B, tests)
-static int g_use_oc = -1;       // adk_set_option("conv_oc16") / ADK_CONV_OC16=0: the last conv_out and the output conv stay two launches
-static int g_use_cw = -1;       // adk_set_option("conv_cin1w") / ADK_CONV_CIN1W=0: the encoder's ring write stays a launch of its own
+// run-time options: read once from the environment (read_env), set by adk_set_option from any host thread -- atomics, like the rvq and conv options
+static std::atomic<int> g_use_rl{-1};       // ADK_CONV_RL=0 disables the rows-in-LDS kernel in AUTO mode (tuning aid)
+static std::atomic<int> g_use_up{-1};       // ADK_CONV_UP16=0 disables the up-sampling streamer in AUTO mode (tuning aid)
+static std::atomic<int> g_use_chain{-1};    // ADK_CHAIN=0: residual chains run op by op (A/B against the per-op kernels)
+static std::atomic<int> g_chain_max_c{-1};  // adk_set_option("chain_max_channels") / ADK_CHAIN_MAXC
+static std::atomic<int> g_chain_min_c{-1};  // adk_set_option("chain_min_channels") / ADK_CHAIN_MINC
+static std::atomic<int> g_chain_min_blocks{-1};   // adk_set_option("chain_min_blocks") / ADK_CHAIN_MIN_BLOCKS: fewer (stream, group) workgroups -> per-op launches
+static std::atomic<int> g_use_ou{-1};       // adk_set_option("conv_ou16") / ADK_CONV_OU16=0: conv_out and the last up-sampler stay two launches (A/B, tests)
+static std::atomic<int> g_use_oc{-1};       // adk_set_option("conv_oc16") / ADK_CONV_OC16=0: the last conv_out and the output conv stay two launches
+static std::atomic<int> g_use_cw{-1};       // adk_set_option("conv_cin1w") / ADK_CONV_CIN1W=0: the encoder's ring write stays a launch of its own
 
 static bool is_split16(int impl) {
     return impl == ADK_IMPL_SPLIT16 || impl == ADK_IMPL_SPLIT16_ROWS || impl == ADK_IMPL_SPLIT16_SK || impl == ADK_IMPL_SPLIT16_UP;
