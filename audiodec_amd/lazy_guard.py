@@ -110,25 +110,31 @@ class CallLog:
         self._drain = drain if drain is not None else (lambda: torch.cuda.synchronize(device) if device is not None else torch.cuda.synchronize())
         self.lock = threading.RLock()
         self.pending = collections.deque()
+        self._units = {}           # program -> hops of its steps in `pending` (what a repair would have to rewind)
         self.in_redo = False
         self.verified = 0          # calls found clean (or repaired)
         self.repairs = 0
         self.waits = 0             # times a call had to wait for the oldest one at its entry (rings / log full)
 
     # ---- bookkeeping ----
-    @staticmethod
-    def _budget(prog):
-        return (prog.rewind_depth + 1) * prog.max_frames
+    # (this runs once per direct call on the host's issue path -- four times per frame for a single stream, where the host, not the device,
+    # sets the pace: plain loops and a running count per program instead of generator expressions over the whole log)
+    def _retire(self, c):
+        units = self._units
+        for prog, frames, _t in c.steps:
+            units[prog] = units.get(prog, 0) - frames
+        self.verified += 1
 
-    def _units(self, prog):
-        return sum(f for c in self.pending for (p, f, _t) in c.steps if p is prog)
+    def _units_of(self, prog):
+        return self._units.get(prog, 0)
 
     def collect(self, block=False):
         """Retire the calls at the head of the log whose posts have completed; block=True waits for every one."""
         with self.lock:
-            while self.pending:
-                c = self.pending[0]
-                found = []
+            pending = self.pending
+            while pending:
+                c = pending[0]
+                found = None
                 for prog, _frames, ticket in c.steps:
                     done, fl = prog.poll_flags(ticket, block)
                     if not done:
@@ -136,12 +142,14 @@ class CallLog:
                             break                            # (what was read is gone from the word: handle it now)
                         return False
                     if fl:
+                        if found is None:
+                            found = []
                         found.append((prog, fl))
                 if found:
                     self._recover(found)
                     return True
-                self.pending.popleft()
-                self.verified += 1
+                pending.popleft()
+                self._retire(c)
             return True
 
     def settle(self):
@@ -152,18 +160,30 @@ class CallLog:
             if self.pending:
                 self.collect(block=True)
 
+    def _full(self, progs, frames):
+        if len(self.pending) >= MAX_PENDING:
+            return True
+        units = self._units
+        for p in progs:
+            if units.get(p, 0) + frames > (p.rewind_depth + 1) * p.max_frames:
+                return True
+        return False
+
     def make_room(self, progs, frames):
         """Before a call that steps each of `progs` by `frames` hops: retire what has completed; wait for the oldest call while a
         program's rings could not be rewound by this call on top of its unverified ones, or the log is full."""
+        pending = self.pending
+        if not pending:
+            return
         self.collect(block=False)
-        while self.pending and (len(self.pending) >= MAX_PENDING or any(self._units(p) + frames > self._budget(p) for p in progs)):
+        while pending and self._full(progs, frames):
             self.waits += 1
-            c = self.pending[0]
+            c = pending[0]
             for prog, _f, ticket in c.steps:
                 prog.poll_flags(ticket, True)
             if not c.steps:                                  # a call without program steps at the head: nothing to wait for
-                self.pending.popleft()
-                self.verified += 1
+                pending.popleft()
+                self._retire(c)
                 continue
             self.collect(block=False)
 
@@ -175,16 +195,22 @@ class CallLog:
             own = False
             pargs = []
             for a in args:
-                lg = log_of(a)
-                if lg is self:
-                    own = True
-                elif lg is not None:
-                    lg.settle()
-                pargs.append(plain(a))
-            if progs and frames > min(self._budget(p) for p in progs):
-                # longer than the rings can be rewound by (a whole utterance in one call): checked synchronously, step by step
-                self.settle()
-                return impl(*pargs)
+                if type(a) is GuardedTensor:
+                    d = a.__dict__
+                    lg = d.get("_adk_log")
+                    if lg is self:
+                        own = True
+                    elif lg is not None:
+                        lg.settle()
+                    pa = d.get("_adk_plain")
+                    a = pa if pa is not None else plain(a)
+                pargs.append(a)
+            if progs:
+                for p in progs:
+                    if frames > (p.rewind_depth + 1) * p.max_frames:
+                        # longer than the rings can be rewound by (a whole utterance in one call): checked synchronously, step by step
+                        self.settle()
+                        return impl(*pargs)
             self.make_room(progs, frames)
             steps = []
             gen._defer = steps
@@ -192,6 +218,10 @@ class CallLog:
                 out = impl(*pargs)
             finally:
                 gen._defer = None
+            if steps:
+                units = self._units
+                for prog, f, _t in steps:
+                    units[prog] = units.get(prog, 0) + f
             self.pending.append(_Call(gen, impl, pargs, out, steps, external_replay and not own))
             return GuardedTensor.wrap(out, self)
 
@@ -211,6 +241,7 @@ class CallLog:
                 if fl:
                     by_prog[prog] = by_prog.get(prog, 0) | fl
         self.pending.clear()
+        self._units.clear()
         other = 0
         for fl in by_prog.values():
             other |= fl & ~native.FLAG_F16_OVERFLOW
