@@ -87,7 +87,8 @@ def test_argument_validation_without_device(lib):
 def test_named_options_validate_their_values(lib):
     """adk_set_option is host state only (no device): known names take their documented values, anything else is ADK_ERR_ARG with a message."""
     for name, good, bad in ((b"rvq_rows", (0, 2, 4, 1), (3, -1, 8)), (b"rvq_v4_min", (1, 192), ()), (b"chain_min_blocks", (160, 0), ()),
-                            (b"chain_max_channels", (64, 128), ()), (b"gv16_max_columns", (256, 0, 32), ())):
+                            (b"chain_max_channels", (64, 128), ()), (b"gv16_max_columns", (256, 0, 32), ()),
+                            (b"conv_ou16", (0, 1), ()), (b"conv_oc16", (0, 1), ()), (b"conv_cin1w", (0, 1), ())):
         for v in good:
             assert lib.adk_set_option(name, v) == 0, (name, v, lib.adk_last_error())
         for v in bad:
