@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 LIB = os.environ.get("ADK_OU16_TRACE_LIB") or os.path.join(ROOT, "tools", "dbg", "ou1", "libaudiodec_hip.so")
 
 
-EXTRA = []
+EXTRA = os.environ.get("ADK_OU16_TRACE_FLAGS", "").split()
 
 
 def build():
