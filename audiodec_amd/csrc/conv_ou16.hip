@@ -350,7 +350,10 @@ __global__ __launch_bounds__(512, 2) void conv_ou16_w8_kernel(ConvArgs a1, ConvA
                 const unsigned off = (out_base + (unsigned)r2 * row_bytes + (unsigned)(ml - ph * a2.cout_real) * 4u) | oob_mask;
                 u32x4o pv;
                 pv.x = __float_as_uint(v.x); pv.y = __float_as_uint(v.y); pv.z = __float_as_uint(v.z); pv.w = __float_as_uint(v.w);
-                __builtin_amdgcn_raw_buffer_store_b128(pv, rsrc_out, off, 0, 0);
+                // sc1 = write-through: the 64-byte pieces (four lanes per step and m-tile) leave the L2 while the launch runs instead of in its
+                // end-of-kernel write-back -- 11.3 -> 11.0 us by rocprofv3, nothing changes in the three-stream schedule (sessions r6_s27.sh,
+                // r6_s29.sh); nt is slower, and the same policy on conv_up16's 32-byte pieces costs 27 -> 42 us (r6_s28.sh)
+                __builtin_amdgcn_raw_buffer_store_b128(pv, rsrc_out, off, 0, 16 /* sc1 */);
             }
         }
     }
