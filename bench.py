@@ -188,7 +188,7 @@ def _rocprof_name(dom):
     if m:
         return ("conv_up16_kernel<",)
     if dom.startswith("conv_ou16<"):
-        return ("conv_ou16_",)                       # conv_ou16_dma_kernel<ACT, MT2> since round 6 (conv_ou16_kernel<...> before)
+        return ("conv_ou16_",)                       # conv_ou16_w8_kernel<ACT, MT2> (round 6; conv_ou16_dma_kernel / conv_ou16_kernel before)
     return None
 
 
